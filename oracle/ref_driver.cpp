@@ -1,0 +1,66 @@
+// oracle/ref_driver.cpp
+//
+// TEST INFRASTRUCTURE ONLY.  Thin extern "C" driver around the REFERENCE'S OWN
+// headers, compiled where they lie (-I/root/reference/include) by
+// oracle/Makefile into oracle/_ref/libspmv_ref.so.  No reference source is
+// copied into this repository; this file only instantiates and calls:
+//   LoadCoo / ToCsr      include/load.hpp:268-408, :420-474
+//   SpMV_cpu_navie       include/spmv/cpu_navie.hpp:5-17
+// The two standard headers below come first because load.hpp uses std::cerr and
+// std::numeric_limits without including them (load.hpp:279, :302).
+//
+// LoadCoo calls exit(1) / throws on malformed input; ref_load() is therefore
+// only ever given well-formed files (error paths are pinned by reading, see
+// tests/test_oracle.py).
+
+#include <iostream>
+#include <limits>
+#include <cstdint>
+#include <cstring>
+
+#include "load.hpp"
+#include "spmv/cpu_navie.hpp"
+
+namespace {
+template <typename off_t, typename val_t>
+struct Held {
+    csr_t<int, off_t, val_t> csr;
+};
+}  // namespace
+
+extern "C" {
+
+#define REF_TYPED(SUF, OFF, VAL)                                                               \
+    void* ref_load_##SUF(const char* path) {                                                   \
+        try {                                                                                  \
+            auto* h = new Held<OFF, VAL>();                                                    \
+            h->csr = ToCsr(LoadCoo<int, OFF, VAL>(std::string(path)));                         \
+            return h;                                                                          \
+        } catch (...) {                                                                        \
+            return nullptr;                                                                    \
+        }                                                                                      \
+    }                                                                                          \
+    void ref_dims_##SUF(void* hp, int64_t* n_rows, int64_t* n_cols, int64_t* nnz) {            \
+        auto* h = static_cast<Held<OFF, VAL>*>(hp);                                            \
+        *n_rows = h->csr.number_of_rows;                                                       \
+        *n_cols = h->csr.number_of_columns;                                                    \
+        *nnz = h->csr.number_of_nonzeros;                                                      \
+    }                                                                                          \
+    void ref_copy_##SUF(void* hp, OFF* Ap, int* Aj, VAL* Ax) {                                 \
+        auto* h = static_cast<Held<OFF, VAL>*>(hp);                                            \
+        memcpy(Ap, h->csr.row_offsets.data(), h->csr.row_offsets.size() * sizeof(OFF));        \
+        memcpy(Aj, h->csr.column_indices.data(), h->csr.column_indices.size() * sizeof(int));  \
+        memcpy(Ax, h->csr.nonzero_values.data(), h->csr.nonzero_values.size() * sizeof(VAL));  \
+    }                                                                                          \
+    void ref_free_##SUF(void* hp) { delete static_cast<Held<OFF, VAL>*>(hp); }                 \
+    void ref_spmv_cpu_##SUF(int n_rows, int n_cols, OFF nnz, const OFF* Ap, const int* Aj,     \
+                            const VAL* Ax, const VAL* x, VAL* y) {                             \
+        SpMV_cpu_navie<int, OFF, VAL, VAL, VAL>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);        \
+    }
+
+REF_TYPED(i32_f32, int, float)
+REF_TYPED(i32_f64, int, double)
+REF_TYPED(i64_f32, long long, float)
+REF_TYPED(i64_f64, long long, double)
+
+}  // extern "C"

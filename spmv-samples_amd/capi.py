@@ -1,0 +1,165 @@
+"""ctypes binding of libmi355spmv.so (the C ABI of include/mi355_spmv.h).
+
+This is plumbing for tests and bench.py: torch provides device memory and
+streams, the library does the work.  There is NO fallback: if the shared library
+is missing or a call fails, a RuntimeError is raised.
+
+The reference interface this mirrors (same argument order and meaning):
+    SpMV(kind_str, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y)   include/spmv.h:29-34
+"""
+import ctypes as C
+import os
+
+import torch  # imported before the library so both share one HIP runtime
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi355spmv.so")
+
+KINDS = {"vector": 0, "merge": 1, "light": 2}
+# labels the C++ host header registers in SPMV_KINDS (host/spmv.h)
+LABELS = {"hip_vector": "vector", "hip_merge": "merge", "hip_light": "light"}
+OFF_TYPES = {torch.int32: (0, "i32"), torch.int64: (1, "i64")}
+VAL_TYPES = {torch.float32: (0, "f32"), torch.float64: (1, "f64")}
+PLAN_REUSE_STRUCTURE = 1
+
+EXPORTS = (
+    ["mi355_spmv_%s_%s_%s" % (k, o, v) for k in KINDS for o in ("i32", "i64") for v in ("f32", "f64")]
+    + ["mi355_spmv_plan_create", "mi355_spmv_plan_execute", "mi355_spmv_plan_destroy",
+       "mi355_spmv_plan_get_info", "mi355_spmv_stream_synchronize", "mi355_spmv_plan_merge_coords", "mi355_spmv_version",
+       "mi355_spmv_status_string", "mi355_spmv_last_error", "mi355_spmv_device_count"]
+)
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("off_type", C.c_int32), ("val_type", C.c_int32),
+                ("lanes_per_row", C.c_int32), ("elems_per_lane", C.c_int32), ("block_threads", C.c_int32),
+                ("grid_blocks", C.c_int64), ("tile_items", C.c_int64), ("n_tiles", C.c_int64),
+                ("rows_per_chunk", C.c_int64), ("scratch_bytes", C.c_int64), ("n_kernels", C.c_int32),
+                ("main_kernel", C.c_char * 64)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["main_kernel"] = d["main_kernel"].decode()
+        return d
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.mi355_spmv_status_string.restype = C.c_char_p
+        L.mi355_spmv_last_error.restype = C.c_char_p
+        L.mi355_spmv_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int32,
+                                             C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        L.mi355_spmv_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi355_spmv_plan_destroy.argtypes = [C.c_void_p]
+        L.mi355_spmv_plan_get_info.argtypes = [C.c_void_p, C.POINTER(PlanInfo)]
+        L.mi355_spmv_plan_merge_coords.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(status, what):
+    if status != 0:
+        L = lib()
+        raise RuntimeError("%s failed: %s (%s)" % (
+            what, L.mi355_spmv_status_string(status).decode(), L.mi355_spmv_last_error().decode()))
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("mi355 spmv takes device tensors only (no CPU path exists)")
+        if not t.is_contiguous():
+            raise RuntimeError("mi355 spmv takes contiguous tensors")
+
+
+def _stream_ptr(stream):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def spmv(kind, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream=None):
+    """One-shot call: the reference's `SpMV(kind_str, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y)`
+    (include/spmv.h:29-34) for kind in {"vector","merge","light"} (or their
+    SPMV_KINDS labels "hip_vector", ...).  Synchronises the stream before returning."""
+    kind = LABELS.get(kind, kind)
+    if kind not in KINDS:
+        # the reference prints 'SpMV kind "<k>" is NOT SUPPROT' and exits (spmv.h:46-47)
+        raise ValueError('SpMV kind "%s" is NOT SUPPORTED' % kind)
+    _require_device(Ap, Aj, Ax, x, y)
+    if Aj.dtype != torch.int32 or Ax.dtype != x.dtype or Ax.dtype != y.dtype:
+        raise TypeError("Aj must be int32 and Ax, x, y one value type")
+    o = OFF_TYPES[Ap.dtype][1]
+    v = VAL_TYPES[Ax.dtype][1]
+    fn = getattr(lib(), "mi355_spmv_%s_%s_%s" % (kind, o, v))
+    nnz_c = C.c_int32(nnz) if o == "i32" else C.c_int64(nnz)
+    st = fn(C.c_int32(n_rows), C.c_int32(n_cols), nnz_c, C.c_void_p(Ap.data_ptr()), C.c_void_p(Aj.data_ptr()),
+            C.c_void_p(Ax.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), _stream_ptr(stream))
+    _check(st, "mi355_spmv_%s_%s_%s" % (kind, o, v))
+    return y
+
+
+class Plan:
+    """Scratch + launch shapes kept across calls (mi355_spmv_plan_*).  Holds
+    references to Ap and Aj so they outlive the plan."""
+
+    def __init__(self, kind, n_rows, n_cols, nnz, Ap, Aj, val_dtype, flags=0):
+        kind = LABELS.get(kind, kind)
+        if kind not in KINDS:
+            raise ValueError('SpMV kind "%s" is NOT SUPPORTED' % kind)
+        _require_device(Ap, Aj)
+        if Aj.dtype != torch.int32:
+            raise TypeError("Aj must be int32")
+        self.kind, self.n_rows, self.n_cols, self.nnz = kind, n_rows, n_cols, nnz
+        self.Ap, self.Aj, self.val_dtype = Ap, Aj, val_dtype
+        self._h = C.c_void_p()
+        st = lib().mi355_spmv_plan_create(C.byref(self._h), KINDS[kind], OFF_TYPES[Ap.dtype][0],
+                                          VAL_TYPES[val_dtype][0], n_rows, n_cols, nnz,
+                                          C.c_void_p(Ap.data_ptr()), C.c_void_p(Aj.data_ptr()), flags)
+        _check(st, "mi355_spmv_plan_create")
+
+    def execute(self, Ax, x, y, stream=None):
+        """Asynchronous on `stream` (default: torch's current stream)."""
+        _require_device(Ax, x, y)
+        if Ax.dtype != self.val_dtype or x.dtype != self.val_dtype or y.dtype != self.val_dtype:
+            raise TypeError("value type differs from the plan's")
+        if Ax.numel() < self.nnz or x.numel() < self.n_cols or y.numel() < self.n_rows:
+            raise ValueError("operand shorter than the plan's sizes")
+        st = lib().mi355_spmv_plan_execute(self._h, C.c_void_p(Ax.data_ptr()), C.c_void_p(x.data_ptr()),
+                                           C.c_void_p(y.data_ptr()), _stream_ptr(stream))
+        _check(st, "mi355_spmv_plan_execute")
+        return y
+
+    def info(self):
+        pi = PlanInfo()
+        _check(lib().mi355_spmv_plan_get_info(self._h, C.byref(pi)), "mi355_spmv_plan_get_info")
+        return pi.as_dict()
+
+    def merge_coords(self):
+        import numpy as np
+        n = self.info()["n_tiles"] + 1
+        rows = np.empty(n, dtype=np.int64)
+        nz = np.empty(n, dtype=np.int64)
+        _check(lib().mi355_spmv_plan_merge_coords(self._h, rows.ctypes.data_as(C.c_void_p),
+                                                  nz.ctypes.data_as(C.c_void_p)), "mi355_spmv_plan_merge_coords")
+        return rows, nz
+
+    def destroy(self):
+        if self._h:
+            lib().mi355_spmv_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

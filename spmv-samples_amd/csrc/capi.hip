@@ -1,0 +1,236 @@
+// capi.hip — the extern "C" surface declared in include/mi355_spmv.h.
+// Plan life cycle, argument checks, type dispatch.  No CPU compute path exists
+// in this library: every entry point either launches HIP kernels or fails.
+
+#include <cstdarg>
+#include <new>
+
+#include "common.hpp"
+
+namespace mi355 {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int plan_alloc_scratch(Plan& p) {
+    const size_t val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
+    size_t off = 0;
+    size_t o_tile_nnz = 0, o_tile_row = 0, o_carry_row = 0, o_carry_val = 0, o_counters = 0;
+    if (p.kind == MI355_KIND_MERGE) {
+        o_tile_nnz = off;  off = align_up(off + sizeof(int64_t) * size_t(p.n_tiles + 1), 256);
+        o_tile_row = off;  off = align_up(off + sizeof(int32_t) * size_t(p.n_tiles + 1), 256);
+        o_carry_row = off; off = align_up(off + sizeof(int32_t) * size_t(p.n_tiles + 1), 256);
+        o_carry_val = off; off = align_up(off + val_bytes * size_t(p.n_tiles + 1), 256);
+    } else if (p.kind == MI355_KIND_LIGHT) {
+        o_counters = off;  off = align_up(off + 128 * size_t(kXcds), 256);
+    }
+    p.scratch_bytes = off;
+    p.scratch = nullptr;
+    if (off) {
+        MI355_HIP_TRY(hipMalloc(&p.scratch, off));
+        char* base = static_cast<char*>(p.scratch);
+        p.tile_nnz = reinterpret_cast<int64_t*>(base + o_tile_nnz);
+        p.tile_row = reinterpret_cast<int32_t*>(base + o_tile_row);
+        p.carry_row = reinterpret_cast<int32_t*>(base + o_carry_row);
+        p.carry_val = base + o_carry_val;
+        p.counters = reinterpret_cast<unsigned long long*>(base + o_counters);
+    }
+    return MI355_SPMV_OK;
+}
+
+template <typename off_t, typename val_t>
+static int execute_typed(Plan& p, const void* Ax, const void* x, void* y, hipStream_t s) {
+    const off_t* Ap = static_cast<const off_t*>(p.Ap);
+    const val_t* ax = static_cast<const val_t*>(Ax);
+    const val_t* xx = static_cast<const val_t*>(x);
+    val_t* yy = static_cast<val_t*>(y);
+    switch (p.kind) {
+        case MI355_KIND_VECTOR: return launch_vector<off_t, val_t>(p, Ap, ax, xx, yy, s);
+        case MI355_KIND_MERGE:  return launch_merge<off_t, val_t>(p, Ap, ax, xx, yy, s);
+        case MI355_KIND_LIGHT:  return launch_light<off_t, val_t>(p, Ap, ax, xx, yy, s);
+    }
+    set_error("unknown kind %d", p.kind);
+    return MI355_SPMV_EINVAL;
+}
+
+static int one_shot(int kind, int off_type, int val_type, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                    const void* Ap, const int32_t* Aj, const void* Ax, const void* x, void* y, void* stream) {
+    mi355_spmv_plan* plan = nullptr;
+    int st = mi355_spmv_plan_create(&plan, kind, off_type, val_type, n_rows, n_cols, nnz, Ap, Aj,
+                                    MI355_PLAN_DEFAULT);
+    if (st != MI355_SPMV_OK) return st;
+    st = mi355_spmv_plan_execute(plan, Ax, x, y, stream);
+    if (st == MI355_SPMV_OK) {
+        hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) {
+            set_error("hipStreamSynchronize -> %s", hipGetErrorString(e));
+            st = MI355_SPMV_EHIP;
+        }
+    }
+    const int st2 = mi355_spmv_plan_destroy(plan);
+    return st != MI355_SPMV_OK ? st : st2;
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+struct mi355_spmv_plan {
+    Plan p;
+};
+
+extern "C" {
+
+int mi355_spmv_version(void) { return MI355_SPMV_VERSION; }
+
+const char* mi355_spmv_status_string(int status) {
+    switch (status) {
+        case MI355_SPMV_OK: return "ok";
+        case MI355_SPMV_EINVAL: return "invalid argument";
+        case MI355_SPMV_ENOTSUP: return "not supported";
+        case MI355_SPMV_EHIP: return "HIP runtime error";
+        case MI355_SPMV_ENOMEM: return "out of device memory";
+        case MI355_SPMV_ENODEV: return "no gfx950 device";
+    }
+    return "unknown status";
+}
+
+const char* mi355_spmv_last_error(void) { return g_err; }
+
+int mi355_spmv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int found = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++found;
+    }
+    return found;
+}
+
+int mi355_spmv_plan_create(mi355_spmv_plan** out, int kind, int off_type, int val_type, int32_t n_rows,
+                           int32_t n_cols, int64_t nnz, const void* Ap, const int32_t* Aj, int flags) {
+    g_err[0] = 0;
+    if (!out) { set_error("plan_create: null plan pointer"); return MI355_SPMV_EINVAL; }
+    *out = nullptr;
+    if (kind < 0 || kind >= MI355_KIND_COUNT) { set_error("plan_create: unknown kind %d", kind); return MI355_SPMV_EINVAL; }
+    if (off_type != MI355_OFF_I32 && off_type != MI355_OFF_I64) { set_error("plan_create: unknown offset type %d", off_type); return MI355_SPMV_EINVAL; }
+    if (val_type != MI355_VAL_F32 && val_type != MI355_VAL_F64) { set_error("plan_create: unknown value type %d", val_type); return MI355_SPMV_EINVAL; }
+    if (n_rows < 0 || n_cols < 0 || nnz < 0) { set_error("plan_create: negative size"); return MI355_SPMV_EINVAL; }
+    if (off_type == MI355_OFF_I32 && nnz > INT32_MAX) { set_error("plan_create: nnz does not fit 32-bit offsets"); return MI355_SPMV_EINVAL; }
+    if (n_rows > 0 && !Ap) { set_error("plan_create: null Ap"); return MI355_SPMV_EINVAL; }
+    if (nnz > 0 && !Aj) { set_error("plan_create: null Aj"); return MI355_SPMV_EINVAL; }
+    if (nnz > 0 && n_cols == 0) { set_error("plan_create: nonzeros but no columns"); return MI355_SPMV_EINVAL; }
+
+    mi355_spmv_plan* h = new (std::nothrow) mi355_spmv_plan();
+    if (!h) { set_error("plan_create: host allocation failed"); return MI355_SPMV_ENOMEM; }
+    Plan& p = h->p;
+    memset(&p, 0, sizeof(p));
+    p.kind = kind; p.off_type = off_type; p.val_type = val_type; p.flags = flags;
+    p.n_rows = n_rows; p.n_cols = n_cols; p.nnz = nnz; p.Ap = Ap; p.Aj = Aj;
+    p.elems_per_lane = 4;
+    switch (kind) {
+        case MI355_KIND_VECTOR: shape_vector(p); break;
+        case MI355_KIND_MERGE:  shape_merge(p); break;
+        case MI355_KIND_LIGHT:  shape_light(p); break;
+    }
+    const int st = plan_alloc_scratch(p);
+    if (st != MI355_SPMV_OK) { delete h; return st; }
+    *out = h;
+    return MI355_SPMV_OK;
+}
+
+int mi355_spmv_plan_execute(mi355_spmv_plan* h, const void* Ax, const void* x, void* y, void* stream) {
+    g_err[0] = 0;
+    if (!h) { set_error("plan_execute: null plan"); return MI355_SPMV_EINVAL; }
+    Plan& p = h->p;
+    if (p.nnz > 0 && (!Ax || !x)) { set_error("plan_execute: null Ax or x"); return MI355_SPMV_EINVAL; }
+    if (p.n_rows > 0 && !y) { set_error("plan_execute: null y"); return MI355_SPMV_EINVAL; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (p.off_type == MI355_OFF_I32) {
+        return p.val_type == MI355_VAL_F32 ? execute_typed<int32_t, float>(p, Ax, x, y, s)
+                                           : execute_typed<int32_t, double>(p, Ax, x, y, s);
+    }
+    return p.val_type == MI355_VAL_F32 ? execute_typed<int64_t, float>(p, Ax, x, y, s)
+                                       : execute_typed<int64_t, double>(p, Ax, x, y, s);
+}
+
+int mi355_spmv_plan_destroy(mi355_spmv_plan* h) {
+    if (!h) return MI355_SPMV_OK;
+    int st = MI355_SPMV_OK;
+    if (h->p.scratch) {
+        hipError_t e = hipFree(h->p.scratch);
+        if (e != hipSuccess) { set_error("hipFree -> %s", hipGetErrorString(e)); st = MI355_SPMV_EHIP; }
+    }
+    delete h;
+    return st;
+}
+
+int mi355_spmv_stream_synchronize(void* stream) {
+    g_err[0] = 0;
+    MI355_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return MI355_SPMV_OK;
+}
+
+int mi355_spmv_plan_get_info(const mi355_spmv_plan* h, mi355_spmv_plan_info* info) {
+    if (!h || !info) { set_error("plan_get_info: null argument"); return MI355_SPMV_EINVAL; }
+    const Plan& p = h->p;
+    memset(info, 0, sizeof(*info));
+    info->kind = p.kind; info->off_type = p.off_type; info->val_type = p.val_type;
+    info->lanes_per_row = p.lanes_per_row;
+    info->elems_per_lane = p.elems_per_lane;
+    info->block_threads = kBlock;
+    info->grid_blocks = p.grid_blocks;
+    info->tile_items = p.tile_items;
+    info->n_tiles = p.n_tiles;
+    info->rows_per_chunk = p.rows_per_chunk;
+    info->scratch_bytes = (int64_t)p.scratch_bytes;
+    info->n_kernels = p.n_kernels;
+    snprintf(info->main_kernel, sizeof(info->main_kernel), "%s", p.main_kernel);
+    return MI355_SPMV_OK;
+}
+
+int mi355_spmv_plan_merge_coords(mi355_spmv_plan* h, int64_t* tile_row, int64_t* tile_nnz) {
+    if (!h || !tile_row || !tile_nnz) { set_error("plan_merge_coords: null argument"); return MI355_SPMV_EINVAL; }
+    Plan& p = h->p;
+    if (p.kind != MI355_KIND_MERGE) { set_error("plan_merge_coords: not a merge plan"); return MI355_SPMV_EINVAL; }
+    if (!p.coords_valid) { set_error("plan_merge_coords: no execute yet"); return MI355_SPMV_EINVAL; }
+    MI355_HIP_TRY(hipDeviceSynchronize());
+    const size_t n = size_t(p.n_tiles + 1);
+    int32_t* rows32 = new (std::nothrow) int32_t[n];
+    if (!rows32) return MI355_SPMV_ENOMEM;
+    hipError_t e = hipMemcpy(rows32, p.tile_row, n * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(tile_nnz, p.tile_nnz, n * sizeof(int64_t), hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < n; ++i) tile_row[i] = rows32[i];
+    delete[] rows32;
+    if (e != hipSuccess) { set_error("hipMemcpy -> %s", hipGetErrorString(e)); return MI355_SPMV_EHIP; }
+    return MI355_SPMV_OK;
+}
+
+#define MI355_SPMV_DEFINE(KIND, KINDENUM, SUF, OFF, OFFENUM, VAL, VALENUM)                            \
+    int mi355_spmv_##KIND##_##SUF(int32_t n_rows, int32_t n_cols, OFF nnz, const OFF* Ap,             \
+                                  const int32_t* Aj, const VAL* Ax, const VAL* x, VAL* y, void* st) { \
+        return one_shot(KINDENUM, OFFENUM, VALENUM, n_rows, n_cols, (int64_t)nnz, Ap, Aj, Ax, x, y, st); \
+    }
+#define MI355_SPMV_DEFINE_KIND(KIND, KINDENUM)                                                 \
+    MI355_SPMV_DEFINE(KIND, KINDENUM, i32_f32, int32_t, MI355_OFF_I32, float, MI355_VAL_F32)   \
+    MI355_SPMV_DEFINE(KIND, KINDENUM, i32_f64, int32_t, MI355_OFF_I32, double, MI355_VAL_F64)  \
+    MI355_SPMV_DEFINE(KIND, KINDENUM, i64_f32, int64_t, MI355_OFF_I64, float, MI355_VAL_F32)   \
+    MI355_SPMV_DEFINE(KIND, KINDENUM, i64_f64, int64_t, MI355_OFF_I64, double, MI355_VAL_F64)
+
+MI355_SPMV_DEFINE_KIND(vector, MI355_KIND_VECTOR)
+MI355_SPMV_DEFINE_KIND(merge, MI355_KIND_MERGE)
+MI355_SPMV_DEFINE_KIND(light, MI355_KIND_LIGHT)
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// common.hpp — shared declarations of the MI355X CSR SpMV engine (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/mi355_spmv.h"
+
+namespace mi355 {
+
+constexpr int kWave = 64;            // gfx950 wavefront width
+constexpr int kBlock = 256;          // 4 waves per workgroup
+constexpr int kXcds = 8;             // XCDs per MI355X, each with a private L2
+constexpr int kCus = 256;            // compute units per MI355X
+
+void set_error(const char* fmt, ...);
+
+#define MI355_HIP_TRY(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ::mi355::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,             \
+                               hipGetErrorString(_e));                                   \
+            return (_e == hipErrorOutOfMemory) ? MI355_SPMV_ENOMEM : MI355_SPMV_EHIP;    \
+        }                                                                                \
+    } while (0)
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
+// L2).  Rows/tiles that are neighbours in memory gather overlapping windows of
+// x, so give every XCD one CONTIGUOUS range of work: logical id = f(blockIdx).
+// Bijective for any grid size.  Speed only; results never depend on placement.
+__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned bid, unsigned nblocks) {
+    const unsigned per = nblocks / kXcds, rem = nblocks % kXcds;
+    const unsigned xcd = bid % kXcds, k = bid / kXcds;
+    // XCDs [0, rem) own per+1 blocks, the rest own per.
+    const unsigned base = xcd * per + (xcd < rem ? xcd : rem);
+    return base + k;
+}
+
+struct Plan {
+    int kind, off_type, val_type, flags;
+    int32_t n_rows, n_cols;
+    int64_t nnz;
+    const void* Ap;
+    const int32_t* Aj;
+    // launch shape
+    int lanes_per_row;     // T
+    int elems_per_lane;    // 1 or 4
+    int64_t grid_blocks;
+    // merge-path
+    int64_t tile_items, n_tiles;
+    bool coords_valid;
+    // dynamic rows
+    int64_t rows_per_chunk;
+    // scratch
+    void* scratch;
+    size_t scratch_bytes;
+    int32_t* tile_row;     // [n_tiles + 1]
+    int64_t* tile_nnz;     // [n_tiles + 1]
+    int32_t* carry_row;    // [n_tiles]
+    void* carry_val;       // [n_tiles] of value type
+    unsigned long long* counters;  // LIGHT: kXcds shards, one 128-B line each
+    int n_kernels;
+    char main_kernel[64];
+};
+
+// kernel launchers (one translation unit per kind)
+template <typename off_t, typename val_t>
+int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s);
+template <typename off_t, typename val_t>
+int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s);
+template <typename off_t, typename val_t>
+int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s);
+
+void shape_vector(Plan& p);
+void shape_merge(Plan& p);
+void shape_light(Plan& p);
+
+}  // namespace mi355

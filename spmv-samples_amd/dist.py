@@ -1,0 +1,68 @@
+"""Row-block sharding of one CSR SpMV across the GPUs of a node.
+
+The reference is single-GPU (main.cu:53, common.cuh:8; no collective anywhere).
+Rows of y = A x are independent (cpu_navie.hpp:9-16), so the matrix is cut into P
+contiguous row blocks, one per rank (one process per GPU); x is replicated and the
+y slices are concatenated with an allgatherv over RCCL/xGMI — SURVEY.md §8(e).
+
+  partition_rows   nnz-balanced cut points from Ap (binary search), so R-MAT-like
+                   skew does not leave one GPU with most of the nonzeros
+  shard_csr        rank p's slice: Ap rebased to 0, Aj/Ax slice (global column
+                   ids kept), so the slice is an ordinary CSR matrix for the C ABI
+  allgatherv       RCCL has no allgatherv: equal counts -> one all_gather into the
+                   full vector; unequal -> one broadcast per root into its
+                   displacement (grouped, asynchronous), the pattern SURVEY §5 names
+
+Backend-agnostic (nccl = RCCL on ROCm for GPUs, gloo for the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def partition_rows(Ap, parts, balance="nnz"):
+    """Cut points r_0=0 <= r_1 <= ... <= r_P=n_rows.
+    balance="nnz": Ap[r_p] ~ p*nnz/P;  "rows": equal row counts."""
+    n_rows = Ap.numel() - 1
+    if balance == "rows":
+        return [n_rows * p // parts for p in range(parts + 1)]
+    nnz = int(Ap[-1].item())
+    targets = torch.tensor([nnz * p // parts for p in range(1, parts)], dtype=Ap.dtype, device=Ap.device)
+    mid = torch.searchsorted(Ap.contiguous(), targets, right=False).tolist() if parts > 1 else []
+    cuts = [0] + [min(int(m), n_rows) for m in mid] + [n_rows]
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts
+
+
+def shard_csr(Ap, Aj, Ax, r0, r1):
+    """Rows [r0, r1) as a stand-alone CSR (local Ap starts at 0, global column ids)."""
+    base = Ap[r0]
+    lo, hi = int(base.item()), int(Ap[r1].item())
+    Ap_l = (Ap[r0:r1 + 1] - base).contiguous()
+    # .clone(): a fresh allocation is 256-byte aligned, which the 16-byte-per-lane
+    # loads of the kernels rely on (an offset view of the parent array is not)
+    return Ap_l, Aj[lo:hi].clone(), Ax[lo:hi].clone()
+
+
+def allgatherv(y_local, y_full, cuts, group=None):
+    """y_full[cuts[p]:cuts[p+1]] <- rank p's y_local, on every rank."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = [cuts[p + 1] - cuts[p] for p in range(world)]
+    assert y_local.numel() == counts[rank]
+    if world == 1:
+        y_full[cuts[0]:cuts[1]].copy_(y_local)
+        return y_full
+    if len(set(counts)) == 1 and y_full.numel() == counts[0] * world:
+        dist.all_gather_into_tensor(y_full, y_local, group=group)
+        return y_full
+    y_full[cuts[rank]:cuts[rank + 1]].copy_(y_local)
+    works = []
+    for p in range(world):
+        if counts[p] == 0:
+            continue
+        src = dist.get_global_rank(group, p) if group is not None else p
+        works.append(dist.broadcast(y_full[cuts[p]:cuts[p + 1]], src=src, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    return y_full

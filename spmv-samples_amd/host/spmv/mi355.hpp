@@ -1,0 +1,82 @@
+// spmv/mi355.hpp — the MI355X kinds, in the shape the reference asks of a new kind
+// (reference README.md:28-45): a function template
+//     SpMV_<name>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y)
+// with the five type parameters of include/spmv.h:29-34, device pointers owned by
+// the caller, y overwritten.  Each kind is a thin shim over the C ABI of
+// include/mi355_spmv.h (libmi355spmv.so holds the HIP kernels):
+//
+//   SpMV_hip_vector   CSR-vector, sub-wave reduction   (cf. SpMV_cusp_warp_reduce,
+//                                                       cusp_warp_reduce.cuh:138-147)
+//   SpMV_hip_merge    merge-path                       (cf. SpMV_merge_based,
+//                                                       merge_based.cuh:22-56)
+//   SpMV_hip_light    dynamic row distribution         (cf. SpMV_light_warp,
+//                                                       LightSpMV.cuh:400-416)
+//
+// Life cycle per call = the reference's: scratch is created before and released
+// after the launch (LightSpMV.cuh:383-395), Timer::kernel_start/stop bracket launch
+// + synchronise (cusp_warp_reduce.cuh:130-132), the null stream is used
+// (main.cu:87-88 relies on it).  A device error aborts with file:line like
+// checkCudaErr (common.cuh:13-23).
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "../../../include/mi355_spmv.h"
+#include "../timer.hpp"
+
+namespace mi355_host {
+
+inline void check(int status, const char* what, const char* file, int line) {
+    if (status != MI355_SPMV_OK) {
+        std::fprintf(stderr, "MI355 SpMV error at %s:%d code=%d(%s) \"%s\" : %s\n", file, line, status,
+                     mi355_spmv_status_string(status), what, mi355_spmv_last_error());
+        std::abort();
+    }
+}
+#define MI355_CHECK(expr) ::mi355_host::check((expr), #expr, __FILE__, __LINE__)
+
+template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,
+          typename vec_y_value_t>
+void run_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap, const index_t* Aj,
+              const mat_value_t* Ax, const vec_x_value_t* x, vec_y_value_t* y) {
+    static_assert(std::is_same<index_t, int>::value || std::is_same<index_t, int32_t>::value,
+                  "mi355 kinds: index_t must be a 32-bit int (reference main.cu:15)");
+    static_assert(sizeof(offset_t) == 4 || sizeof(offset_t) == 8, "mi355 kinds: offset_t must be 32- or 64-bit");
+    static_assert(std::is_integral<offset_t>::value && std::is_signed<offset_t>::value,
+                  "mi355 kinds: offset_t must be a signed integer");
+    static_assert(std::is_same<mat_value_t, vec_x_value_t>::value && std::is_same<mat_value_t, vec_y_value_t>::value,
+                  "mi355 kinds: A, x and y share one value type (reference main.cu:17)");
+    static_assert(std::is_same<mat_value_t, float>::value || std::is_same<mat_value_t, double>::value,
+                  "mi355 kinds: value type is float or double");
+    const int off_type = sizeof(offset_t) == 8 ? MI355_OFF_I64 : MI355_OFF_I32;
+    const int val_type = std::is_same<mat_value_t, double>::value ? MI355_VAL_F64 : MI355_VAL_F32;
+
+    mi355_spmv_plan* plan = nullptr;
+    MI355_CHECK(mi355_spmv_plan_create(&plan, kind, off_type, val_type, (int32_t)n_rows, (int32_t)n_cols,
+                                       (int64_t)nnz, Ap, reinterpret_cast<const int32_t*>(Aj), MI355_PLAN_DEFAULT));
+    Timer::kernel_start();
+    MI355_CHECK(mi355_spmv_plan_execute(plan, Ax, x, y, /*stream=*/nullptr));
+    MI355_CHECK(mi355_spmv_stream_synchronize(/*stream=*/nullptr));
+    Timer::kernel_stop();
+    MI355_CHECK(mi355_spmv_plan_destroy(plan));
+}
+
+}  // namespace mi355_host
+
+#define MI355_DEFINE_KIND(NAME, KIND)                                                                          \
+    template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,               \
+              typename vec_y_value_t>                                                                          \
+    void NAME(index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap, const index_t* Aj,             \
+              const mat_value_t* Ax, const vec_x_value_t* x, vec_y_value_t* y) {                               \
+        ::mi355_host::run_kind(KIND, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);                                   \
+    }
+
+/// CSR-vector SpMV with per-row sub-wave (wave64) reduction
+MI355_DEFINE_KIND(SpMV_hip_vector, MI355_KIND_VECTOR)
+/// merge-path load-balanced SpMV (search -> tile -> deterministic fix-up)
+MI355_DEFINE_KIND(SpMV_hip_merge, MI355_KIND_MERGE)
+/// LightSpMV-style dynamic row distribution (sharded atomic row counters)
+MI355_DEFINE_KIND(SpMV_hip_light, MI355_KIND_LIGHT)

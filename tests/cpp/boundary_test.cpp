@@ -1,0 +1,125 @@
+// tests/cpp/boundary_test.cpp — exercises the C++ operator boundary
+// (spmv-samples_amd/host/spmv.h) the way the reference's harness does
+// (main.cu:48-97): device arrays owned by the caller, SpMV(kind, ...) per label,
+// copy y back, compare with a serial CSR loop.  TEST CODE: the serial loop below is
+// the checker, not a product path.
+//
+//   boundary_test                 all labels x {i32,i64} x {f32,f64}; exit 0 when all pass
+//   boundary_test --bad-label     calls SpMV("no_such_kind", ...): must print the
+//                                 reference's message and exit(EXIT_FAILURE) (spmv.h:46-47)
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../spmv-samples_amd/host/spmv.h"
+
+#define HIP_OK(e)                                                                   \
+    do {                                                                            \
+        hipError_t _e = (e);                                                        \
+        if (_e != hipSuccess) {                                                     \
+            std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(_e)); \
+            std::exit(2);                                                           \
+        }                                                                           \
+    } while (0)
+
+static unsigned long long lcg(unsigned long long& s) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    return s >> 33;
+}
+
+template <typename offset_t, typename value_t>
+static int run_combo(const char* combo, int n_rows, int n_cols, int max_len) {
+    using index_t = int;
+    unsigned long long seed = 12345;
+    std::vector<offset_t> Ap(n_rows + 1, 0);
+    std::vector<index_t> Aj;
+    std::vector<value_t> Ax;
+    for (int r = 0; r < n_rows; ++r) {
+        int len = (r % 7 == 3) ? 0 : int(lcg(seed) % (unsigned)(max_len + 1));
+        if (r == n_rows / 2) len = 40 * max_len;  // one long row
+        for (int k = 0; k < len; ++k) {
+            Aj.push_back(index_t(lcg(seed) % (unsigned)n_cols));
+            Ax.push_back(value_t(double(lcg(seed) % 2001) / 1000.0 - 1.0));
+        }
+        Ap[r + 1] = offset_t(Aj.size());
+    }
+    const offset_t nnz = offset_t(Aj.size());
+    std::vector<value_t> x(n_cols);
+    for (int c = 0; c < n_cols; ++c) x[c] = value_t(double(lcg(seed) % 2001) / 1000.0 - 1.0);
+
+    std::vector<double> ref(n_rows), mag(n_rows);
+    for (int r = 0; r < n_rows; ++r) {
+        double s = 0, a = 0;
+        for (offset_t k = Ap[r]; k < Ap[r + 1]; ++k) {
+            double p = double(Ax[k]) * double(x[Aj[k]]);
+            s += p;
+            a += std::fabs(p);
+        }
+        ref[r] = s;
+        mag[r] = a;
+    }
+
+    offset_t* dAp; index_t* dAj; value_t *dAx, *dX, *dY;
+    HIP_OK(hipMalloc((void**)&dAp, (n_rows + 1) * sizeof(offset_t)));
+    HIP_OK(hipMalloc((void**)&dAj, (size_t(nnz) + 1) * sizeof(index_t)));
+    HIP_OK(hipMalloc((void**)&dAx, (size_t(nnz) + 1) * sizeof(value_t)));
+    HIP_OK(hipMalloc((void**)&dX, n_cols * sizeof(value_t)));
+    HIP_OK(hipMalloc((void**)&dY, n_rows * sizeof(value_t)));
+    HIP_OK(hipMemcpy(dAp, Ap.data(), (n_rows + 1) * sizeof(offset_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dAj, Aj.data(), size_t(nnz) * sizeof(index_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dAx, Ax.data(), size_t(nnz) * sizeof(value_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dX, x.data(), n_cols * sizeof(value_t), hipMemcpyHostToDevice));
+
+    const double eps = std::is_same<value_t, float>::value ? std::ldexp(1.0, -24) : std::ldexp(1.0, -53);
+    int failures = 0;
+    std::vector<value_t> y(n_rows);
+#define X(label, func)                                                                                  \
+    {                                                                                                   \
+        /* poison y: a kind that skips a row must not inherit the previous kind's value (quirk 5) */    \
+        std::vector<value_t> poison(n_rows, std::numeric_limits<value_t>::quiet_NaN());                 \
+        HIP_OK(hipMemcpy(dY, poison.data(), n_rows * sizeof(value_t), hipMemcpyHostToDevice));          \
+        SpMV<index_t, offset_t, value_t, value_t, value_t>(label, n_rows, n_cols, nnz, dAp, dAj, dAx, dX, dY); \
+        HIP_OK(hipMemcpy(y.data(), dY, n_rows * sizeof(value_t), hipMemcpyDeviceToHost));               \
+        int bad = 0;                                                                                    \
+        double worst = 0;                                                                               \
+        for (int r = 0; r < n_rows; ++r) {                                                              \
+            const double len = double(Ap[r + 1] - Ap[r]);                                               \
+            const double err = std::fabs(double(y[r]) - ref[r]);                                        \
+            const double bound = (len + 2) * eps * mag[r];                                              \
+            if (!(err <= bound)) ++bad;                                                                 \
+            if (err > worst) worst = err;                                                               \
+        }                                                                                               \
+        std::printf("[%-10s] %-8s rows=%d nnz=%lld max_err=%.3e bad_rows=%d total=%lldus kernel=%lldus\n", \
+                    label, combo, n_rows, (long long)nnz, worst, bad, (long long)Timer::total_cost(),   \
+                    (long long)Timer::kernel_cost());                                                   \
+        failures += bad ? 1 : 0;                                                                        \
+        if (Timer::kernel_cost() > Timer::total_cost()) { std::printf("timer order violated\n"); ++failures; } \
+    }
+    SPMV_KINDS
+#undef X
+    HIP_OK(hipFree(dAp)); HIP_OK(hipFree(dAj)); HIP_OK(hipFree(dAx)); HIP_OK(hipFree(dX)); HIP_OK(hipFree(dY));
+    return failures;
+}
+
+int main(int argc, char** argv) {
+    HIP_OK(hipSetDevice(0));  // USED_DEVICE 0 (common.cuh:8)
+    if (argc > 1 && std::strcmp(argv[1], "--bad-label") == 0) {
+        int* d;
+        HIP_OK(hipMalloc((void**)&d, 64));
+        SpMV<int, int, float, float, float>("no_such_kind", 1, 1, 0, d, d, (float*)d, (float*)d, (float*)d);
+        return 0;  // not reached: SpMV exits with EXIT_FAILURE
+    }
+    int failures = 0;
+    failures += run_combo<int, float>("i32_f32", 3001, 2500, 24);
+    failures += run_combo<int, double>("i32_f64", 3001, 2500, 24);
+    failures += run_combo<long long, float>("i64_f32", 3001, 2500, 24);
+    failures += run_combo<long long, double>("i64_f64", 777, 1, 3);  // n_cols == 1
+    std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
+    return failures ? 1 : 0;
+}
