@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void merge_search_kernel(
 }
 
 // ---- K7: one tile per workgroup ---------------------------------------------------
-template <int IPT, typename off_t, typename val_t>
+template <int IPT, bool VEC, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     int32_t n_rows, int64_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     int32_t* __restrict__ carry_row, val_t* __restrict__ carry_val) {
     constexpr int TILE = kBlock * IPT;
     using v4 = typename Vec4<val_t>::type;
-    __shared__ __attribute__((aligned(16))) val_t s_nz[TILE + 4];  // products, index = nnz - (y0 & ~3)
+    __shared__ __attribute__((aligned(32))) val_t s_nz[TILE + 4];  // products, index = nnz - (y0 & ~3)
     __shared__ int s_re[TILE + 1];                                 // tile-relative row ends
     __shared__ val_t s_part[TILE];                                 // sums of the rows ending here
     __shared__ val_t s_wave_sum[kBlock / kWave];
@@ -88,10 +88,14 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     const int64_t y0 = tile_nnz[t], y1 = tile_nnz[t + 1];
     const int tr = x1 - x0;            // rows that end in this tile
     const int tn = int(y1 - y0);       // nonzeros in this tile
-    const int shift = int(y0 & 3);
+    const int shift = VEC ? int(y0 & 3) : 0;
     const int64_t yb = y0 - shift;     // 16-byte aligned start of the stream
 
     // (1) products a*x for the tile's nonzeros, 4 per lane per load
+    if constexpr (!VEC) {
+        // Aj / Ax not 16-byte aligned (an offset view): 4-byte-per-lane form
+        for (int i = tid; i < tn; i += kBlock) s_nz[i] = Ax[y0 + i] * x[Aj[y0 + i]];
+    } else
     for (int g = tid; 4 * g < tn + shift; g += kBlock) {
         const int64_t j = yb + 4 * int64_t(g);
         int4v c;
@@ -223,10 +227,7 @@ void shape_merge(Plan& p) {
 template <typename off_t, typename val_t>
 int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s) {
     if (p.n_rows == 0 || p.n_tiles == 0) return MI355_SPMV_OK;
-    if (((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax)) & 15u) != 0) {
-        set_error("merge: Aj and Ax must be 16-byte aligned");
-        return MI355_SPMV_EINVAL;
-    }
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax)) & 15u) == 0;
     const bool reuse = (p.flags & MI355_PLAN_REUSE_STRUCTURE) && p.coords_valid;
     if (!reuse) {
         const unsigned g = unsigned((p.n_tiles + 1 + kBlock - 1) / kBlock);
@@ -235,9 +236,15 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
         MI355_HIP_TRY(hipGetLastError());
         p.coords_valid = true;
     }
-    hipLaunchKernelGGL((merge_tile_kernel<kMergeIpt, off_t, val_t>), dim3((unsigned)p.n_tiles), dim3(kBlock), 0,
-                       s, p.n_rows, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz, p.carry_row,
-                       static_cast<val_t*>(p.carry_val));
+    if (aligned) {
+        hipLaunchKernelGGL((merge_tile_kernel<kMergeIpt, true, off_t, val_t>), dim3((unsigned)p.n_tiles),
+                           dim3(kBlock), 0, s, p.n_rows, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz,
+                           p.carry_row, static_cast<val_t*>(p.carry_val));
+    } else {
+        hipLaunchKernelGGL((merge_tile_kernel<kMergeIpt, false, off_t, val_t>), dim3((unsigned)p.n_tiles),
+                           dim3(kBlock), 0, s, p.n_rows, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz,
+                           p.carry_row, static_cast<val_t*>(p.carry_val));
+    }
     MI355_HIP_TRY(hipGetLastError());
     if (p.n_tiles > 1) {
         const unsigned g = unsigned((p.n_tiles + kBlock - 1) / kBlock);

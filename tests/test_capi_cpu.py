@@ -1,0 +1,82 @@
+"""CPU suite, part 2: the C-ABI library loads without a GPU and exports every symbol
+include/mi355_spmv.h declares; argument checks that need no device; the Python
+binding refuses host tensors (there is no CPU compute path)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mi355_spmv.h")).read()
+    names = set(re.findall(r"\b(mi355_spmv_[a-z_0-9]+)\s*\(", text))
+    names.discard("mi355_spmv_plan")
+    # the one-shot family is declared through a macro
+    for kind in re.findall(r"MI355_SPMV_DECLARE_KIND\((\w+)\)", text):
+        if kind == "KIND":
+            continue
+        for suf in ("i32_f32", "i32_f64", "i64_f32", "i64_f64"):
+            names.add("mi355_spmv_%s_%s" % (kind, suf))
+    return {n for n in names if "##" not in n}
+
+
+def test_library_exports_every_declared_symbol(sp):
+    lib = sp.capi.lib()
+    decl = declared_symbols()
+    assert len(decl) >= 12 + 9
+    missing = [s for s in sorted(decl) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(sp.capi.EXPORTS) == decl
+
+
+def test_version_and_status_strings(sp):
+    lib = sp.capi.lib()
+    assert lib.mi355_spmv_version() == 100
+    assert lib.mi355_spmv_status_string(0) == b"ok"
+    assert lib.mi355_spmv_status_string(1) == b"invalid argument"
+    assert lib.mi355_spmv_status_string(99) == b"unknown status"
+
+
+def test_plan_create_rejects_bad_arguments_without_touching_the_device(sp):
+    lib = sp.capi.lib()
+    h = C.c_void_p()
+    dummy = C.c_void_p(256)
+    bad = [
+        (7, 0, 0, 4, 4, 4, dummy, dummy),       # unknown kind
+        (0, 5, 0, 4, 4, 4, dummy, dummy),       # unknown offset type
+        (0, 0, 9, 4, 4, 4, dummy, dummy),       # unknown value type
+        (0, 0, 0, -1, 4, 4, dummy, dummy),      # negative rows
+        (0, 0, 0, 4, 4, -1, dummy, dummy),      # negative nnz
+        (0, 0, 0, 4, 4, 2 ** 31, dummy, dummy), # nnz beyond 32-bit offsets
+        (0, 0, 0, 4, 4, 4, None, dummy),        # null Ap
+        (0, 0, 0, 4, 4, 4, dummy, None),        # null Aj
+        (0, 0, 0, 4, 0, 4, dummy, dummy),       # nonzeros but no columns
+    ]
+    for kind, ot, vt, nr, nc, nnz, Ap, Aj in bad:
+        st = lib.mi355_spmv_plan_create(C.byref(h), kind, ot, vt, nr, nc, nnz, Ap, Aj, 0)
+        assert st == 1, (kind, ot, vt, nr, nc, nnz)
+        assert not h.value
+        assert lib.mi355_spmv_last_error() != b""
+    assert lib.mi355_spmv_plan_execute(None, None, None, None, None) == 1
+    assert lib.mi355_spmv_plan_destroy(None) == 0
+
+
+def test_binding_refuses_host_tensors_and_unknown_kinds(sp):
+    Ap = torch.tensor([0, 1], dtype=torch.int32)
+    Aj = torch.tensor([0], dtype=torch.int32)
+    Ax = torch.ones(1)
+    with pytest.raises(RuntimeError, match="device tensors only"):
+        sp.spmv("vector", 1, 1, 1, Ap, Aj, Ax, Ax, Ax.clone())
+    with pytest.raises(ValueError, match="NOT SUPPORTED"):
+        sp.spmv("cusparse", 1, 1, 1, Ap, Aj, Ax, Ax, Ax.clone())
+
+
+def test_missing_library_fails_loudly(sp, monkeypatch):
+    monkeypatch.setattr(sp.capi, "_lib", None)
+    monkeypatch.setattr(sp.capi, "LIB_PATH", "/nonexistent/libmi355spmv.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sp.capi.lib()

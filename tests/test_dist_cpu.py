@@ -1,0 +1,110 @@
+"""CPU suite, part 4: the N>1 path (row partition, shard, allgatherv) with gloo, world_size 2.
+The per-rank SpMV here is the ORACLE (test infrastructure standing in for the GPU
+kernel, which cannot run in this container); tests/test_gpu_dist.py runs the same
+flow with the HIP path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, random_csr
+
+
+def test_partition_rows_balances_nnz(sp):
+    rng = np.random.RandomState(0)
+    Ap, _, _ = random_csr(rng, 1000, 50, 20, long_row=30000)
+    Ap_t = torch.from_numpy(Ap)
+    for parts in (1, 2, 3, 8):
+        cuts = sp.dist.partition_rows(Ap_t, parts)
+        assert cuts[0] == 0 and cuts[-1] == 1000 and len(cuts) == parts + 1
+        assert all(a <= b for a, b in zip(cuts, cuts[1:]))
+    cuts = sp.dist.partition_rows(Ap_t, 2)
+    left = int(Ap[cuts[1]])
+    assert abs(left - Ap[-1] / 2) <= 30000                          # within one (long) row of the target
+    assert sp.dist.partition_rows(Ap_t, 4, balance="rows") == [0, 250, 500, 750, 1000]
+
+
+def test_shard_csr_is_a_standalone_matrix(sp, oracle):
+    rng = np.random.RandomState(1)
+    Ap, Aj, Ax = random_csr(rng, 400, 70, 25)
+    x = (rng.rand(70) * 2 - 1).astype(np.float32)
+    y = oracle.spmv_serial(Ap, Aj, Ax, x)
+    cuts = sp.dist.partition_rows(torch.from_numpy(Ap), 3)
+    parts = []
+    for p in range(3):
+        a, j, v = sp.dist.shard_csr(torch.from_numpy(Ap), torch.from_numpy(Aj), torch.from_numpy(Ax),
+                                    cuts[p], cuts[p + 1])
+        assert int(a[0]) == 0 and int(a[-1]) == j.numel() == v.numel()
+        parts.append(oracle.spmv_serial(a.numpy(), j.numpy(), v.numpy(), x))
+    assert np.array_equal(np.concatenate(parts), y)                 # row-local: bit-exact
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, balance, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as g
+    from oracle.oracle import Oracle
+    sp = g.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.RandomState(5)                                   # same matrix on every rank
+    Ap, Aj, Ax = random_csr(rng, 1001, 333, 30, long_row=4000)
+    x = (rng.rand(333) * 2 - 1).astype(np.float32)
+    Ap_t, Aj_t, Ax_t = map(torch.from_numpy, (Ap, Aj, Ax))
+    cuts = sp.dist.partition_rows(Ap_t, world, balance=balance)
+    a, j, v = sp.dist.shard_csr(Ap_t, Aj_t, Ax_t, cuts[rank], cuts[rank + 1])
+    y_local = torch.from_numpy(Oracle().spmv_serial(a.numpy(), j.numpy(), v.numpy(), x))
+    y_full = torch.full((1001,), float("nan"))
+    sp.dist.allgatherv(y_local, y_full, cuts)
+    want = Oracle().spmv_serial(Ap, Aj, Ax, x)
+    ok = np.array_equal(y_full.numpy(), want)
+    open(os.path.join(out_dir, "rank%d.%s" % (rank, "ok" if ok else "bad")), "w").close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("balance", ["nnz", "rows"])
+def test_allgatherv_world2_gloo(tmp_path, balance):
+    """nnz balance gives unequal counts (broadcast-per-root path); 'rows' on 1001 rows too;
+    both must reproduce the single-process y bit for bit on every rank."""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, balance, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["rank0.ok", "rank1.ok"]
+
+
+def _worker_equal(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    sp = g.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cuts = [0, 8, 16]
+    y_local = torch.arange(8, dtype=torch.float32) + 100 * rank
+    y_full = torch.zeros(16)
+    sp.dist.allgatherv(y_local, y_full, cuts)                        # equal counts: all_gather path
+    want = torch.cat([torch.arange(8.0), torch.arange(8.0) + 100])
+    ok = torch.equal(y_full, want)
+    open(os.path.join(out_dir, "rank%d.%s" % (rank, "ok" if ok else "bad")), "w").close()
+    dist.destroy_process_group()
+
+
+def test_allgatherv_equal_counts_world2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_equal, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["rank0.ok", "rank1.ok"]

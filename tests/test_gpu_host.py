@@ -1,0 +1,93 @@
+"""GPU suite: the C++ operator boundary (spmv-samples_amd/host/spmv.h) driven like the
+reference's harness (main.cu:48-97), and the 2-rank row-sharded flow with the HIP path."""
+import os
+import socket
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, random_csr
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "tests", "cpp", "boundary_test")
+
+
+def _build_exe():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "spmv-samples_amd", "csrc")], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+
+
+def test_cpp_boundary_all_labels_and_types():
+    """SpMV<index_t,offset_t,value_t,...>(label, ...) for every row of SPMV_KINDS and the
+    four type combinations, y poisoned between kinds, Timer::kernel_cost <= total_cost."""
+    _build_exe()
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ALL PASSED" in r.stdout
+    for label in ("hip_vector", "hip_merge", "hip_light"):
+        assert r.stdout.count("[%-10s]" % label) == 4
+
+
+def test_cpp_boundary_unknown_label_exits_like_the_reference():
+    """spmv.h:46-47: message on stderr and exit(EXIT_FAILURE)."""
+    _build_exe()
+    r = subprocess.run([EXE, "--bad-label"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1
+    assert 'SpMV kind "no_such_kind" is NOT SUPPROT' in r.stderr
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, kind, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as g
+    from oracle.oracle import Oracle
+    sp = g.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    # both ranks share the box's single GPU; the collective runs over gloo on host copies
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(5)
+    Ap, Aj, Ax = random_csr(rng, 40001, 3000, 30, long_row=50000)
+    x = (rng.rand(3000) * 2 - 1).astype(np.float32)
+    Ap_t, Aj_t, Ax_t = (torch.from_numpy(a).to(dev) for a in (Ap, Aj, Ax))
+    cuts = sp.dist.partition_rows(Ap_t, world)
+    a, j, v = sp.dist.shard_csr(Ap_t, Aj_t, Ax_t, cuts[rank], cuts[rank + 1])
+    n_local = cuts[rank + 1] - cuts[rank]
+    y_local = torch.full((n_local,), float("nan"), device=dev)
+    sp.spmv(kind, n_local, 3000, int(j.numel()), a, j, v, torch.from_numpy(x).to(dev), y_local)
+    y_full = torch.full((40001,), float("nan"))
+    sp.dist.allgatherv(y_local.cpu(), y_full, cuts)
+    # single-GPU result of the same kind on the whole matrix
+    y_one = torch.full((40001,), float("nan"), device=dev)
+    sp.spmv(kind, 40001, 3000, int(Ap[-1]), Ap_t, Aj_t, Ax_t, torch.from_numpy(x).to(dev), y_one)
+    orc = Oracle()
+    y64, yabs = orc.spmv_ref64(Ap, Aj, Ax, x)
+    bound = (np.diff(Ap) + 2) * 2.0 ** -24 * yabs
+    ok = bool(np.all(np.abs(y_full.numpy().astype(np.float64) - y64) <= bound))
+    if kind != "merge":  # row-local kinds: the sharded result equals the 1-GPU result bit for bit
+        ok = ok and bool(torch.equal(y_full, y_one.cpu()))
+    open(os.path.join(out_dir, "rank%d.%s" % (rank, "ok" if ok else "bad")), "w").close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["vector", "merge", "light"])
+def test_two_rank_row_sharded_spmv(tmp_path, kind):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["rank0.ok", "rank1.ok"]

@@ -1,0 +1,293 @@
+"""GPU suite: the HIP path (through the C ABI) against the oracle.
+
+Bar (north_star): Ap/Aj handling and every integer-valued case
+bit-exact; floating point inside the per-row bound
+    |y_gpu[r] - y64[r]| <= (len_r + 2) * eps * sum_k |Ax[k] x[Aj[k]]|,
+eps = 2^-24 (fp32) / 2^-53 (fp64), y64 = fp64 serial sum — valid for any summation
+order and FMA use.  y is NaN-poisoned before every call, so a
+skipped row cannot pass.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, parity_bound, random_csr, seeded_x, unhex
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["vector", "merge", "light"]
+COMBOS = [("i32", "f32"), ("i32", "f64"), ("i64", "f32"), ("i64", "f64")]
+NP = {"i32": np.int32, "i64": np.int64, "f32": np.float32, "f64": np.float64}
+FIXTURES = sorted(f for f in os.listdir(GOLD) if f.endswith(".mtx"))
+DEV = "cuda:0"
+
+
+def gpu_spmv(sp, kind, n_cols, Ap, Aj, Ax, x, plan=False, flags=0):
+    """numpy in, numpy out, through the C ABI; y poisoned with NaN first."""
+    n_rows = len(Ap) - 1
+    nnz = int(Ap[-1]) if n_rows >= 0 and len(Ap) else 0
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    dAp, dAj, dAx, dx = d(Ap), d(Aj), d(Ax), d(x)
+    y = torch.full((max(n_rows, 0),), float("nan"), dtype=dAx.dtype, device=DEV)
+    if plan:
+        p = sp.Plan(kind, n_rows, n_cols, nnz, dAp, dAj, dAx.dtype, flags)
+        p.execute(dAx, dx, y)
+        torch.cuda.synchronize()
+        p.destroy()
+    else:
+        sp.spmv(kind, n_rows, n_cols, nnz, dAp, dAj, dAx, dx, y)
+    return y.cpu().numpy()
+
+
+def assert_parity(oracle, Ap, Aj, Ax, x, y, exact=False):
+    assert not np.any(np.isnan(y)), "a row was skipped (NaN poison survived)"
+    if exact:
+        assert np.array_equal(y, oracle.spmv_serial(Ap, Aj, Ax, x))
+        return
+    y64, bound = parity_bound(oracle, Ap, Aj, Ax, x)
+    err = np.abs(y.astype(np.float64) - y64)
+    bad = np.nonzero(err > bound)[0]
+    assert bad.size == 0, "rows outside the bound: %s (err %s, bound %s)" % (bad[:5], err[bad[:5]], bound[bad[:5]])
+
+
+# ---- the reference's own inputs/outputs (golden vectors made from its build) -----------------
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("off,val", COMBOS)
+def test_golden_fixtures(sp, oracle, golden, kind, off, val):
+    for name in FIXTURES:
+        nr, nc, Ap, Aj, Ax = oracle.load_mtx(os.path.join(GOLD, name), off, val)
+        g = golden[name]
+        for xname, x in (("y_ones", np.ones(nc, dtype=NP[val])), ("y_seeded", seeded_x(nc, NP[val]))):
+            y = gpu_spmv(sp, kind, nc, Ap, Aj, Ax, x)
+            want = unhex(g[val][xname], NP[val])
+            assert not np.any(np.isnan(y)), name
+            integer_valued = name in ("pat3x4_dup_unsorted.mtx", "lattice9_cub_doc.mtx", "int5_general.mtx")
+            if integer_valued and xname == "y_ones":
+                assert np.array_equal(y, want), name                 # bit-exact
+            else:
+                y64, bound = parity_bound(oracle, Ap, Aj, Ax, x)
+                assert np.all(np.abs(y.astype(np.float64) - y64) <= bound), name
+                assert np.all(np.abs(want.astype(np.float64) - y64) <= bound), name
+
+
+# ---- ragged random matrices: empty rows, duplicates, unsorted columns, one long row ----------
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("off,val", COMBOS)
+@pytest.mark.parametrize("shape", [(1, 1, 1, None), (5, 3, 2, None), (257, 100, 9, None), (4099, 700, 40, 30000),
+                                   (20011, 5000, 6, 9000), (3000, 1, 2, None), (1500, 2000, 300, None)])
+def test_random_ragged(sp, oracle, kind, off, val, shape):
+    n_rows, n_cols, max_len, long_row = shape
+    rng = np.random.RandomState(n_rows * 7 + max_len)
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, max_len, NP[off], NP[val], long_row=long_row)
+    x = (rng.rand(n_cols) * 2 - 1).astype(NP[val])
+    assert_parity(oracle, Ap, Aj, Ax, x, gpu_spmv(sp, kind, n_cols, Ap, Aj, Ax, x))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("off,val", COMBOS)
+def test_integer_valued_is_bit_exact(sp, oracle, kind, off, val):
+    """Small integers sum exactly in any order -> the GPU result must equal the serial
+    CPU result bit for bit (pattern matrices with x = 1)."""
+    rng = np.random.RandomState(99)
+    Ap, Aj, Ax = random_csr(rng, 6007, 900, 50, NP[off], NP[val], long_row=20000, integer_values=True)
+    x = rng.randint(-2, 3, size=900).astype(NP[val])
+    assert_parity(oracle, Ap, Aj, Ax, x, gpu_spmv(sp, kind, 900, Ap, Aj, Ax, x), exact=True)
+
+
+# ---- edge cases ---------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_empty_and_degenerate(sp, oracle, kind):
+    f32 = np.float32
+    # no rows at all: a no-op that must not fail
+    y = gpu_spmv(sp, kind, 5, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, f32), np.ones(5, f32))
+    assert y.shape == (0,)
+    # rows but no nonzeros: y = 0 everywhere (cpu_navie.hpp:10-15)
+    y = gpu_spmv(sp, kind, 5, np.zeros(1001, np.int32), np.zeros(0, np.int32), np.zeros(0, f32), np.ones(5, f32))
+    assert np.array_equal(y, np.zeros(1000, f32))
+    # every nonzero in the last row
+    Ap = np.zeros(301, np.int32); Ap[-1] = 7777
+    rng = np.random.RandomState(4)
+    Aj = rng.randint(0, 50, 7777).astype(np.int32)
+    Ax = rng.randint(-3, 4, 7777).astype(f32)
+    x = rng.randint(-2, 3, 50).astype(f32)
+    assert_parity(oracle, Ap, Aj, Ax, x, gpu_spmv(sp, kind, 50, Ap, Aj, Ax, x), exact=True)
+    # every nonzero in the first row, then empty rows only
+    Ap = np.full(301, 7777, np.int32); Ap[0] = 0
+    assert_parity(oracle, Ap, Aj, Ax, x, gpu_spmv(sp, kind, 50, Ap, Aj, Ax, x), exact=True)
+    # one row, one column
+    y = gpu_spmv(sp, kind, 1, np.array([0, 3], np.int32), np.zeros(3, np.int32), np.array([1, 2, 4], f32),
+                 np.array([3], f32))
+    assert y.tolist() == [21.0]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_nan_and_inf_propagate_only_to_their_rows(sp, kind):
+    """A NaN/Inf in x must reach exactly the rows that reference it (masked lanes of the
+    16-byte loads must not leak a neighbour's value)."""
+    rng = np.random.RandomState(8)
+    Ap, Aj, Ax = random_csr(rng, 2000, 64, 11)
+    Ax[:] = 1.0
+    x = np.ones(64, np.float32)
+    x[13] = np.nan
+    y = gpu_spmv(sp, kind, 64, Ap, Aj, Ax, x)
+    touched = np.zeros(2000, bool)
+    for r in range(2000):
+        touched[r] = np.any(Aj[Ap[r]:Ap[r + 1]] == 13)
+    assert np.array_equal(np.isnan(y), touched)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_unaligned_views_take_the_4_byte_path(sp, oracle, kind):
+    """Aj/Ax that are not 16-byte aligned (offset views of a larger buffer) must still work."""
+    rng = np.random.RandomState(21)
+    Ap, Aj, Ax = random_csr(rng, 3000, 500, 30)
+    x = (rng.rand(500) * 2 - 1).astype(np.float32)
+    nnz = int(Ap[-1])
+    big_j = torch.zeros(nnz + 3, dtype=torch.int32, device=DEV)
+    big_x = torch.zeros(nnz + 3, dtype=torch.float32, device=DEV)
+    big_j[1:nnz + 1] = torch.from_numpy(Aj).to(DEV)
+    big_x[3:nnz + 3] = torch.from_numpy(Ax).to(DEV)
+    dAj, dAx = big_j[1:nnz + 1], big_x[3:nnz + 3]
+    assert dAj.data_ptr() % 16 != 0 and dAx.data_ptr() % 16 != 0
+    y = torch.full((3000,), float("nan"), device=DEV)
+    sp.spmv(kind, 3000, 500, nnz, torch.from_numpy(Ap).to(DEV), dAj, dAx, torch.from_numpy(x).to(DEV), y)
+    assert_parity(oracle, Ap, Aj, Ax, x, y.cpu().numpy())
+
+
+# ---- merge-path integers are bit-exact against the restatement of thread_search.cuh ---------
+
+@pytest.mark.parametrize("off", ["i32", "i64"])
+def test_merge_tile_coordinates_bit_exact(sp, oracle, off):
+    rng = np.random.RandomState(17)
+    Ap, Aj, Ax = random_csr(rng, 50021, 1000, 12, NP[off], np.float32, long_row=100000)
+    x = np.ones(1000, np.float32)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    dAp, dAj, dAx, dx = d(Ap), d(Aj), d(Ax), d(x)
+    y = torch.empty(50021, device=DEV)
+    p = sp.Plan("merge", 50021, 1000, int(Ap[-1]), dAp, dAj, torch.float32)
+    info = p.info()
+    p.execute(dAx, dx, y)
+    rows, nz = p.merge_coords()
+    want_rows, want_nz = oracle.merge_tile_coords(Ap, info["tile_items"])
+    assert info["n_tiles"] + 1 == len(want_rows)
+    assert np.array_equal(rows, want_rows) and np.array_equal(nz, want_nz)
+    p.destroy()
+
+
+# ---- determinism, plans, row-local equality -----------------------------------------------------
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_run_to_run_bitwise_reproducible(sp, kind):
+    """Also for merge-path: the fix-up is ordered, not float atomics."""
+    rng = np.random.RandomState(33)
+    Ap, Aj, Ax = random_csr(rng, 30000, 4000, 25, long_row=60000)
+    x = (rng.rand(4000) * 2 - 1).astype(np.float32)
+    a = gpu_spmv(sp, kind, 4000, Ap, Aj, Ax, x)
+    for _ in range(3):
+        assert np.array_equal(a, gpu_spmv(sp, kind, 4000, Ap, Aj, Ax, x))
+
+
+def test_vector_and_light_agree_bitwise(sp):
+    """Both use the same per-row arithmetic; only the row -> wave assignment differs
+    (results are assignment-independent)."""
+    rng = np.random.RandomState(34)
+    Ap, Aj, Ax = random_csr(rng, 25000, 3000, 70, long_row=5000)
+    x = (rng.rand(3000) * 2 - 1).astype(np.float32)
+    assert np.array_equal(gpu_spmv(sp, "vector", 3000, Ap, Aj, Ax, x), gpu_spmv(sp, "light", 3000, Ap, Aj, Ax, x))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("flags", [0, 1])
+def test_plan_reuse_across_executes(sp, oracle, kind, flags):
+    rng = np.random.RandomState(35)
+    Ap, Aj, Ax = random_csr(rng, 9000, 800, 33, long_row=12000)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    dAp, dAj, dAx = d(Ap), d(Aj), d(Ax)
+    p = sp.Plan(kind, 9000, 800, int(Ap[-1]), dAp, dAj, torch.float32, flags)
+    for i in range(4):
+        x = (rng.rand(800) * 2 - 1).astype(np.float32)
+        y = torch.full((9000,), float("nan"), device=DEV)
+        p.execute(dAx, d(x), y)
+        torch.cuda.synchronize()
+        assert_parity(oracle, Ap, Aj, Ax, x, y.cpu().numpy())
+    p.destroy()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_execute_on_a_side_stream(sp, oracle, kind):
+    rng = np.random.RandomState(36)
+    Ap, Aj, Ax = random_csr(rng, 5000, 600, 20)
+    x = (rng.rand(600) * 2 - 1).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    dAp, dAj, dAx, dx = d(Ap), d(Aj), d(Ax), d(x)
+    y = torch.full((5000,), float("nan"), device=DEV)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    p = sp.Plan(kind, 5000, 600, int(Ap[-1]), dAp, dAj, torch.float32)
+    with torch.cuda.stream(s):
+        p.execute(dAx, dx, y)
+    s.synchronize()
+    assert_parity(oracle, Ap, Aj, Ax, x, y.cpu().numpy())
+    p.destroy()
+
+
+# ---- BASELINE-sized inputs ---------------------------------------------------------------------
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_full_size_s32_band_against_oracle(sp, oracle, kind):
+    """North-star target shape (2^22 rows x 32 nnz/row, fp32): every row against the
+    fp64 oracle bound (the oracle takes about a second at this size)."""
+    m = sp.synth.workload("s32-band", DEV)
+    x = sp.synth.dense_vector(m.n_cols, torch.float32, 1, DEV)
+    y = torch.full((m.n_rows,), float("nan"), device=DEV)
+    sp.spmv(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax, x, y)
+    Ap, Aj, Ax = m.numpy()
+    assert_parity(oracle, Ap, Aj, Ax, x.cpu().numpy(), y.cpu().numpy())
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_full_size_powerlaw_pattern_is_exact(sp, kind):
+    """Config C3 stand-in (916 428 rows, 5 105 039 nnz, values 1.0, power-law rows) with
+    x = 1: y must equal the row lengths exactly (bit-exact integer case)."""
+    m = sp.synth.workload("c3-webgoogle", DEV)
+    x = torch.ones(m.n_cols, device=DEV)
+    y = torch.full((m.n_rows,), float("nan"), device=DEV)
+    sp.spmv(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax, x, y)
+    lens = (m.Ap[1:] - m.Ap[:-1]).to(torch.float32)
+    assert lens.max().item() > 1000                                  # it is a load-balance stress
+    assert torch.equal(y, lens)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_full_size_fp64_i64_linearity_and_rowsums(sp, oracle, kind):
+    """Config C4 stand-in (8.4 M rows, ~224 M nnz, fp64 values, 64-bit Ap): size-independent
+    properties — row sums for x = 1 against a torch segment sum, linearity in x — and the
+    first 200 000 rows against the oracle."""
+    m = sp.synth.workload("c4-nlpkkt", DEV)
+    assert m.Ap.dtype == torch.int64 and m.Ax.dtype == torch.float64
+    n = m.n_rows
+    ones = torch.ones(m.n_cols, dtype=torch.float64, device=DEV)
+    y1 = torch.full((n,), float("nan"), dtype=torch.float64, device=DEV)
+    sp.spmv(kind, n, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax, ones, y1)
+    csum = torch.zeros(m.nnz + 1, dtype=torch.float64, device=DEV)
+    torch.cumsum(m.Ax, 0, out=csum[1:])
+    rowsum = csum[m.Ap[1:]] - csum[m.Ap[:-1]]
+    assert torch.allclose(y1, rowsum, rtol=0, atol=1e-9)             # prefix-sum differences: loose but global
+    del csum, rowsum
+    xa = sp.synth.dense_vector(m.n_cols, torch.float64, 5, DEV)
+    xb = sp.synth.dense_vector(m.n_cols, torch.float64, 6, DEV)
+    ya, yb, yc = (torch.empty(n, dtype=torch.float64, device=DEV) for _ in range(3))
+    sp.spmv(kind, n, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax, xa, ya)
+    sp.spmv(kind, n, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax, xb, yb)
+    sp.spmv(kind, n, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax, 2.0 * xa - 0.5 * xb, yc)
+    assert torch.allclose(yc, 2.0 * ya - 0.5 * yb, rtol=0, atol=1e-12 * 28 * 4)
+    rows = 200000
+    hi = int(m.Ap[rows].item())
+    Ap = m.Ap[:rows + 1].cpu().numpy(); Aj = m.Aj[:hi].cpu().numpy(); Ax = m.Ax[:hi].cpu().numpy()
+    y64, bound = parity_bound(oracle, Ap, Aj, Ax, xa.cpu().numpy())
+    assert np.all(np.abs(ya[:rows].cpu().numpy() - y64) <= bound)
