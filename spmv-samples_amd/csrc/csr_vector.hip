@@ -2,20 +2,39 @@
 //
 // Replaces the reference's CUSP CSR-vector family on the hot path
 // (include/spmv/cusp/cusp_warp_reduce.cuh:11-59 kernel, :93-133 width selection,
-// include/spmv/cusp/utils.cuh:38-47 shuffle tree).  Written for gfx950: 64-lane
-// waves, 256-thread workgroups, 16-byte-per-lane loads of Aj/Ax (row_dot.hpp),
-// workgroup -> row-block mapping that keeps neighbouring row blocks on one XCD so
-// that the window of x they share is served by that XCD's L2.
-//
-// One vector of T lanes per row, 256/T rows per workgroup, grid = ceil(rows / that):
-// the reference's launch shape (cusp_warp_reduce.cuh:70-87) scaled to wave64.
+// include/spmv/cusp/utils.cuh:38-47 shuffle tree).  Written for gfx950:
+//   * 64-lane waves, 256-thread workgroups, T lanes per row (T = 2..64);
+//   * 16-byte-per-lane nontemporal loads of Aj/Ax, R rows per vector in flight;
+//   * a workgroup owns a CHUNK of consecutive rows (~32 K nonzeros) and stages the
+//     window of x the chunk touches through LDS (xwindow.hpp) — the plain global
+//     gather is what bounds this kernel on MI355X, not the Aj/Ax stream;
+//   * chunk ids are remapped so each XCD walks a contiguous range of rows and
+//     neighbouring windows of x hit that XCD's L2.
+// The 4-byte-per-lane kernel at the bottom is the form of the reference
+// (one row per vector, grid = ceil(rows / vectors per block), cusp_warp_reduce.cuh:70-87);
+// it is used only when Aj/Ax/x are not 16-byte aligned.
 
 #include "common.hpp"
 #include "row_dot.hpp"
+#include "xwindow.hpp"
 
 namespace mi355 {
 
-template <int T, int ELEMS, typename off_t, typename val_t>
+template <int T, int R, typename off_t, typename val_t>
+__global__ __launch_bounds__(kBlock) void csr_vector_window_kernel(
+    int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
+    const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, int32_t rows_per_chunk) {
+    __shared__ __attribute__((aligned(16))) val_t s_x[kWindowBytes / sizeof(val_t)];
+    __shared__ int s_red[2 * (kBlock / kWave)];
+    const unsigned chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int64_t rb = int64_t(chunk) * rows_per_chunk;
+    const int64_t re = min(rb + rows_per_chunk, int64_t(n_rows));
+    const XWindow<val_t> win = stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, s_x,
+                                                            int32_t(kWindowBytes / sizeof(val_t)), s_red);
+    chunk_rows<T, R, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win);
+}
+
+template <int T, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     int32_t n_rows, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y) {
@@ -24,7 +43,6 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     const int lane = threadIdx.x & (T - 1);
     const int64_t row = int64_t(blk) * ROWS_PER_BLOCK + (threadIdx.x / T);
     const bool live = row < n_rows;
-
     // a vector past the last row runs as an empty row so that every lane of the
     // wave reaches the shuffles below
     off_t start = 0, end = 0;
@@ -32,29 +50,61 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
         start = Ap[row];
         end = Ap[row + 1];
     }
-    val_t sum = row_partial<T, ELEMS, off_t, val_t>(start, end, nnz, lane, Aj, Ax, x);
+    val_t sum = row_partial<T, 1, off_t, val_t>(start, end, nnz, lane, Aj, Ax, x);
     sum = vector_reduce<T, val_t>(sum);
     if (live && lane == 0) y[row] = sum;
 }
 
+template <typename val_t> constexpr int rows_in_flight() { return sizeof(val_t) == 4 ? 4 : 2; }
+
 void shape_vector(Plan& p) {
     p.lanes_per_row = pick_lanes_per_row(p.nnz, p.n_rows, p.elems_per_lane);
-    const int rows_per_block = kBlock / p.lanes_per_row;
-    p.grid_blocks = (int64_t(p.n_rows) + rows_per_block - 1) / rows_per_block;
+    const int R = p.val_type == MI355_VAL_F64 ? rows_in_flight<double>() : rows_in_flight<float>();
+    p.rows_per_chunk = pick_rows_per_chunk(p.nnz, p.n_rows, p.lanes_per_row, R);
+    p.grid_blocks = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
     if (p.grid_blocks < 1) p.grid_blocks = 1;
+    p.n_tiles = p.grid_blocks;
     p.n_kernels = 1;
-    snprintf(p.main_kernel, sizeof(p.main_kernel), "csr_vector_kernel");
+    snprintf(p.main_kernel, sizeof(p.main_kernel), "csr_vector_window_kernel");
 }
 
-template <int ELEMS, typename off_t, typename val_t>
-static int launch_vector_t(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
-                           hipStream_t s) {
+template <typename off_t, typename val_t>
+static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
+                                hipStream_t s) {
+    constexpr int R = rows_in_flight<val_t>();
     const dim3 grid((unsigned)p.grid_blocks), block(kBlock);
     const off_t nnz = (off_t)p.nnz;
-#define MI355_VEC_CASE(TT)                                                                          \
-    case TT:                                                                                        \
-        hipLaunchKernelGGL((csr_vector_kernel<TT, ELEMS, off_t, val_t>), grid, block, 0, s, p.n_rows, \
-                           nnz, Ap, p.Aj, Ax, x, y);                                                \
+#define MI355_VEC_CASE(TT)                                                                             \
+    case TT:                                                                                           \
+        hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, off_t, val_t>), grid, block, 0, s, p.n_rows, \
+                           p.n_cols, nnz, Ap, p.Aj, Ax, x, y, (int32_t)p.rows_per_chunk);              \
+        break;
+    switch (p.lanes_per_row) {
+        MI355_VEC_CASE(2)
+        MI355_VEC_CASE(4)
+        MI355_VEC_CASE(8)
+        MI355_VEC_CASE(16)
+        MI355_VEC_CASE(32)
+        MI355_VEC_CASE(64)
+        default:
+            set_error("csr_vector: bad lanes_per_row %d", p.lanes_per_row);
+            return MI355_SPMV_EINVAL;
+    }
+#undef MI355_VEC_CASE
+    MI355_HIP_TRY(hipGetLastError());
+    return MI355_SPMV_OK;
+}
+
+template <typename off_t, typename val_t>
+static int launch_vector_plain(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
+                               hipStream_t s) {
+    const int rows_per_block = kBlock / p.lanes_per_row;
+    const dim3 grid((unsigned)((int64_t(p.n_rows) + rows_per_block - 1) / rows_per_block)), block(kBlock);
+    const off_t nnz = (off_t)p.nnz;
+#define MI355_VEC_CASE(TT)                                                                                \
+    case TT:                                                                                              \
+        hipLaunchKernelGGL((csr_vector_kernel<TT, off_t, val_t>), grid, block, 0, s, p.n_rows, nnz, Ap, p.Aj, \
+                           Ax, x, y);                                                                     \
         break;
     switch (p.lanes_per_row) {
         MI355_VEC_CASE(2)
@@ -75,11 +125,12 @@ static int launch_vector_t(const Plan& p, const off_t* Ap, const val_t* Ax, cons
 template <typename off_t, typename val_t>
 int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s) {
     if (p.n_rows == 0) return MI355_SPMV_OK;
-    // 16-byte loads need 16-byte-aligned Aj / Ax (hipMalloc gives 256); a caller
+    // 16-byte loads need 16-byte-aligned Aj / Ax / x (hipMalloc gives 256); a caller
     // that passes an offset view gets the 4-byte-per-lane form instead.
-    const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax)) & 15u) == 0;
-    if (p.elems_per_lane == 4 && aligned) return launch_vector_t<4, off_t, val_t>(p, Ap, Ax, x, y, s);
-    return launch_vector_t<1, off_t, val_t>(p, Ap, Ax, x, y, s);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
+                           reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
+    if (aligned) return launch_vector_window<off_t, val_t>(p, Ap, Ax, x, y, s);
+    return launch_vector_plain<off_t, val_t>(p, Ap, Ax, x, y, s);
 }
 
 template int launch_vector<int32_t, float>(const Plan&, const int32_t*, const float*, const float*, float*, hipStream_t);

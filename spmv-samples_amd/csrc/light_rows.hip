@@ -2,36 +2,37 @@
 //
 // Replaces include/spmv/LightSpMV.cuh:111-263 (csrDynamicVector / csrDynamicWarp)
 // and its per-call setup (:266-316).  The idea kept from the reference: a
-// persistent grid whose vectors fetch rows from a global atomic counter, so that
-// rows of very different lengths balance across the chip.
+// persistent grid that fetches rows from a global atomic counter, so that rows of
+// very different lengths balance across the chip.
 //
 // What changes for MI355X:
-//  * one dequeue per WAVE, not per vector: lane 0 adds `rows_per_chunk` to the
-//    counter and the value is broadcast with a scalar readfirstlane; all 64 lanes
-//    stay in the loop and out-of-range vectors are predicated (the reference's
-//    warp-level kernel lets finished vectors leave a loop whose siblings still
-//    shuffle, LightSpMV.cuh:212, :246, :260);
-//  * one returning device-scope atomic on a single word saturates near 88
-//    dequeues/us on this chip, and 1 row per atomic (the reference at T = 8)
-//    would be ~10^5 us for 8.3 M rows, so a dequeue hands out a chunk of rows
-//    sized so the whole SpMV needs ~8 dequeues per resident wave, and the counter
-//    is SHARDED: 8 counters, each on its own 128-byte line, each covering one
-//    contiguous eighth of the rows.  A wave starts on the shard of its XCD
-//    (blockIdx % 8 shares an L2) and walks the other shards when its own runs
-//    dry, so placement only affects speed, never results;
+//  * the unit handed out by one atomic is a CHUNK of consecutive rows taken by a
+//    whole workgroup (the reference hands 1 row to a vector or 32/T rows to a warp,
+//    LightSpMV.cuh:128-132, :205-209).  One returning device-scope atomic on a
+//    single word saturates near 88 dequeues/us on this chip; 1 row per atomic would
+//    cost ~10^5 us for 8.3 M rows.  A chunk also gives the workgroup a window of x
+//    worth staging through LDS (xwindow.hpp), which is what lifts the gather limit;
+//  * the counter is SHARDED: 8 counters, each on its own 128-byte line, each
+//    covering one contiguous eighth of the rows.  A workgroup starts on the shard of
+//    its XCD (blockIdx % 8 shares an L2) and walks the other shards when its own
+//    runs dry, so placement only affects speed, never results;
+//  * lane 0 of the workgroup dequeues, the chunk index reaches the other waves
+//    through LDS + barrier; all lanes stay in the loops and rows past the chunk are
+//    predicated (the reference's warp-level kernel lets finished vectors leave a
+//    loop whose siblings still shuffle, LightSpMV.cuh:212, :246, :260);
 //  * the counters live in the plan's scratch and are zeroed by a memset node on
-//    the stream each call (the reference mallocs, memsets and frees them per
-//    call, LightSpMV.cuh:274-276, :314);
-//  * x is read with plain global loads (no texture path on CDNA; the
-//    reference's texture fetch, LightSpMV.cuh:59-88, has no counterpart);
-//  * the dot product is row_dot.hpp's 16-byte-per-lane form.
+//    the stream each call (the reference mallocs, memsets and frees them per call,
+//    LightSpMV.cuh:274-276, :314);
+//  * x is read with plain loads / the LDS window (no texture path on CDNA; the
+//    reference's texture fetch, LightSpMV.cuh:59-88, has no counterpart).
 //
-// Exit condition: every wave leaves after visiting all 8 shards, each visit ends
-// on the first dequeue at or past the shard's end — reached by every wave
+// Exit condition: a workgroup leaves after visiting all 8 shards; a visit ends on
+// the first dequeue at or past the shard's end, which every workgroup reaches
 // whatever the interleaving, so the grid always drains.
 
 #include "common.hpp"
 #include "row_dot.hpp"
+#include "xwindow.hpp"
 
 namespace mi355 {
 
@@ -43,7 +44,39 @@ __device__ __forceinline__ unsigned long long wave_broadcast_u64(unsigned long l
     return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
-template <int T, int ELEMS, typename off_t, typename val_t>
+template <int T, int R, typename off_t, typename val_t>
+__global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
+    int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
+    const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
+    unsigned long long* __restrict__ counters, int32_t rows_per_chunk) {
+    __shared__ __attribute__((aligned(16))) val_t s_x[kWindowBytes / sizeof(val_t)];
+    __shared__ int s_red[2 * (kBlock / kWave)];
+    __shared__ unsigned long long s_got;
+    const int home = blockIdx.x % kXcds;
+    for (int visit = 0; visit < kXcds; ++visit) {
+        const int shard = (home + visit) % kXcds;
+        const int64_t shard_begin = int64_t(n_rows) * shard / kXcds;
+        const int64_t shard_end = int64_t(n_rows) * (shard + 1) / kXcds;
+        while (true) {
+            if (threadIdx.x == 0) {
+                s_got = atomicAdd(&counters[shard * kCounterStride], (unsigned long long)rows_per_chunk);
+            }
+            __syncthreads();
+            const int64_t chunk_begin = shard_begin + int64_t(wave_broadcast_u64(s_got));
+            if (chunk_begin >= shard_end) break;  // uniform over the workgroup
+            const int64_t chunk_end = min(chunk_begin + rows_per_chunk, shard_end);
+            // (stage_x_window's barriers also order this read of s_got before the next write)
+            const XWindow<val_t> win = stage_x_window<off_t, val_t>(
+                chunk_begin, chunk_end, n_cols, Ap, Aj, x, s_x, int32_t(kWindowBytes / sizeof(val_t)), s_red);
+            chunk_rows<T, R, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win);
+            __syncthreads();  // every wave is done with the window before it is refilled
+        }
+        __syncthreads();      // s_got read by all before the next shard's dequeue overwrites it
+    }
+}
+
+// 4-byte-per-lane form for operands that are not 16-byte aligned: one dequeue per wave.
+template <int T, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void light_rows_kernel(
     int32_t n_rows, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
@@ -53,7 +86,6 @@ __global__ __launch_bounds__(kBlock) void light_rows_kernel(
     const int lane = threadIdx.x & (T - 1);
     const int vec_in_wave = lane64 / T;
     const int home = blockIdx.x % kXcds;
-
     for (int visit = 0; visit < kXcds; ++visit) {
         const int shard = (home + visit) % kXcds;
         const int64_t shard_begin = int64_t(n_rows) * shard / kXcds;
@@ -75,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void light_rows_kernel(
                     start = Ap[row];
                     end = Ap[row + 1];
                 }
-                val_t sum = row_partial<T, ELEMS, off_t, val_t>(start, end, nnz, lane, Aj, Ax, x);
+                val_t sum = row_partial<T, 1, off_t, val_t>(start, end, nnz, lane, Aj, Ax, x);
                 sum = vector_reduce<T, val_t>(sum);
                 if (live && lane == 0) y[row] = sum;
             }
@@ -83,35 +115,66 @@ __global__ __launch_bounds__(kBlock) void light_rows_kernel(
     }
 }
 
+template <typename val_t> constexpr int light_rows_in_flight() { return sizeof(val_t) == 4 ? 4 : 2; }
+
 void shape_light(Plan& p) {
     p.lanes_per_row = pick_lanes_per_row(p.nnz, p.n_rows, p.elems_per_lane);
-    const int rows_per_step = kWave / p.lanes_per_row;
-    // persistent grid: up to 8 workgroups (32 waves) per CU, fewer for small inputs
-    int64_t blocks = (int64_t(p.n_rows) + int64_t(rows_per_step) * 4 * 4 - 1) / (int64_t(rows_per_step) * 4 * 4);
-    if (blocks > int64_t(kCus) * 8) blocks = int64_t(kCus) * 8;
-    if (blocks < 1) blocks = 1;
-    p.grid_blocks = blocks;
-    const int64_t waves = blocks * (kBlock / kWave);
-    int64_t chunk = int64_t(p.n_rows) / (waves * 8);
-    chunk = (chunk + rows_per_step - 1) / rows_per_step * rows_per_step;
-    if (chunk < rows_per_step) chunk = rows_per_step;
-    if (chunk > 4096) chunk = 4096;
+    const int R = p.val_type == MI355_VAL_F64 ? light_rows_in_flight<double>() : light_rows_in_flight<float>();
+    const int64_t pass = int64_t(kBlock / p.lanes_per_row) * R;
+    // chunks: half the size of the static kind's, so that there are >= ~8 per resident
+    // workgroup to balance with, but never below one pass of the workgroup
+    int64_t chunk = pick_rows_per_chunk(p.nnz, p.n_rows, p.lanes_per_row, R) / 2;
+    chunk = (chunk + pass - 1) / pass * pass;
+    if (chunk < pass) chunk = pass;
     p.rows_per_chunk = chunk;
     p.n_tiles = (int64_t(p.n_rows) + chunk - 1) / chunk;
+    // persistent grid: 4 workgroups per CU (LDS window 36 KB each), fewer for small inputs
+    int64_t blocks = p.n_tiles;
+    if (blocks > int64_t(kCus) * 4) blocks = int64_t(kCus) * 4;
+    if (blocks < 1) blocks = 1;
+    p.grid_blocks = blocks;
     p.n_kernels = 1;
-    snprintf(p.main_kernel, sizeof(p.main_kernel), "light_rows_kernel");
+    snprintf(p.main_kernel, sizeof(p.main_kernel), "light_rows_window_kernel");
 }
 
-template <int ELEMS, typename off_t, typename val_t>
-static int launch_light_t(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
-                          hipStream_t s) {
+template <typename off_t, typename val_t>
+static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
+                               hipStream_t s) {
+    constexpr int R = light_rows_in_flight<val_t>();
     const dim3 grid((unsigned)p.grid_blocks), block(kBlock);
     const off_t nnz = (off_t)p.nnz;
     const int32_t chunk = (int32_t)p.rows_per_chunk;
-#define MI355_LIGHT_CASE(TT)                                                                         \
-    case TT:                                                                                         \
-        hipLaunchKernelGGL((light_rows_kernel<TT, ELEMS, off_t, val_t>), grid, block, 0, s, p.n_rows, \
-                           nnz, Ap, p.Aj, Ax, x, y, p.counters, chunk);                              \
+#define MI355_LIGHT_CASE(TT)                                                                             \
+    case TT:                                                                                             \
+        hipLaunchKernelGGL((light_rows_window_kernel<TT, R, off_t, val_t>), grid, block, 0, s, p.n_rows,  \
+                           p.n_cols, nnz, Ap, p.Aj, Ax, x, y, p.counters, chunk);                        \
+        break;
+    switch (p.lanes_per_row) {
+        MI355_LIGHT_CASE(2)
+        MI355_LIGHT_CASE(4)
+        MI355_LIGHT_CASE(8)
+        MI355_LIGHT_CASE(16)
+        MI355_LIGHT_CASE(32)
+        MI355_LIGHT_CASE(64)
+        default:
+            set_error("light_rows: bad lanes_per_row %d", p.lanes_per_row);
+            return MI355_SPMV_EINVAL;
+    }
+#undef MI355_LIGHT_CASE
+    MI355_HIP_TRY(hipGetLastError());
+    return MI355_SPMV_OK;
+}
+
+template <typename off_t, typename val_t>
+static int launch_light_plain(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
+                              hipStream_t s) {
+    const dim3 grid((unsigned)p.grid_blocks), block(kBlock);
+    const off_t nnz = (off_t)p.nnz;
+    const int32_t chunk = (int32_t)p.rows_per_chunk;
+#define MI355_LIGHT_CASE(TT)                                                                          \
+    case TT:                                                                                          \
+        hipLaunchKernelGGL((light_rows_kernel<TT, off_t, val_t>), grid, block, 0, s, p.n_rows, nnz, Ap, \
+                           p.Aj, Ax, x, y, p.counters, chunk);                                        \
         break;
     switch (p.lanes_per_row) {
         MI355_LIGHT_CASE(2)
@@ -133,9 +196,10 @@ template <typename off_t, typename val_t>
 int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s) {
     if (p.n_rows == 0) return MI355_SPMV_OK;
     MI355_HIP_TRY(hipMemsetAsync(p.counters, 0, sizeof(unsigned long long) * kCounterStride * kXcds, s));
-    const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax)) & 15u) == 0;
-    if (p.elems_per_lane == 4 && aligned) return launch_light_t<4, off_t, val_t>(p, Ap, Ax, x, y, s);
-    return launch_light_t<1, off_t, val_t>(p, Ap, Ax, x, y, s);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
+                           reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
+    if (aligned) return launch_light_window<off_t, val_t>(p, Ap, Ax, x, y, s);
+    return launch_light_plain<off_t, val_t>(p, Ap, Ax, x, y, s);
 }
 
 template int launch_light<int32_t, float>(const Plan&, const int32_t*, const float*, const float*, float*, hipStream_t);

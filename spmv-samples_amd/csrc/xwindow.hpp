@@ -1,0 +1,207 @@
+// xwindow.hpp — the dense vector x staged through an LDS window, and the row-chunk
+// body shared by the CSR-vector and the dynamic-row kernels.
+//
+// Why: on gfx950 a wave-wide 4-byte gather whose 64 lanes fall in 64 different
+// cache lines (a banded row: neighbouring nonzeros are ~256 columns apart) is
+// served at about one line per clock by the CU's vector L1; measured on the
+// S32-band target the plain global gather caps the whole SpMV at ~2.5-2.8 TB/s
+// while the same kernel with the gather removed streams at 5.4 TB/s
+// (tools/exp_spmv.hip).  LDS serves 64 arbitrary 4-byte reads in a few cycles.
+// So a workgroup that owns a chunk of consecutive rows first copies the window of
+// x those rows touch into LDS with coalesced 16-byte loads, then gathers from LDS.
+//
+// The window is a software cache, never a correctness assumption:
+//   * its bounds come from a cheap SAMPLE — the first and last column of every row
+//     of the chunk (exact when a row's columns are sorted, which the interface
+//     does not promise: the reference loader keeps file order, load.hpp:443-471);
+//   * every gathered column is range-checked; a column outside the window is
+//     loaded from global memory instead (predicated, skipped when no lane needs it);
+//   * if the sampled span exceeds the LDS capacity the window keeps its low end.
+// The reference has no counterpart (it reads x through the texture path or plain
+// loads: LightSpMV.cuh:59-88, cusp_warp_reduce.cuh:41-48).
+#pragma once
+
+#include <climits>
+#include <type_traits>
+
+#include "common.hpp"
+#include "row_dot.hpp"
+
+namespace mi355 {
+
+template <typename val_t>
+struct XWindow {
+    const val_t* s_x;   // LDS copy of x[lo, lo+len)
+    int32_t lo;
+    int32_t len;
+};
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = min(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+// Workgroup-wide: sample the column range of rows [rb, re), copy that window of x
+// into s_x (capacity `cap` elements).  All kBlock threads must call; ends with a
+// barrier.  s_red: 2 * (kBlock / kWave) ints of LDS scratch.
+template <typename off_t, typename val_t>
+__device__ __forceinline__ XWindow<val_t> stage_x_window(int64_t rb, int64_t re, int32_t n_cols,
+                                                         const off_t* __restrict__ Ap,
+                                                         const int32_t* __restrict__ Aj,
+                                                         const val_t* __restrict__ x, val_t* s_x,
+                                                         int32_t cap, int* s_red) {
+    const int tid = threadIdx.x;
+    int lo = INT32_MAX, hi = -1;
+    for (int64_t r = rb + tid; r < re; r += kBlock) {
+        const off_t s = Ap[r], e = Ap[r + 1];
+        if (e > s) {
+            const int first = Aj[s], last = Aj[e - 1];
+            lo = min(lo, min(first, last));
+            hi = max(hi, max(first, last));
+        }
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((tid & (kWave - 1)) == 0) {
+        s_red[2 * (tid / kWave)] = lo;
+        s_red[2 * (tid / kWave) + 1] = hi;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) {
+        lo = min(lo, s_red[2 * w]);
+        hi = max(hi, s_red[2 * w + 1]);
+    }
+    XWindow<val_t> win;
+    win.s_x = s_x;
+    if (hi < 0) {          // chunk has no nonzeros
+        win.lo = 0;
+        win.len = 0;
+        __syncthreads();
+        return win;
+    }
+    constexpr int PER16 = 16 / int(sizeof(val_t));   // elements per 16-byte load
+    lo &= ~(PER16 - 1);                              // x is 16-byte aligned (checked on the host)
+    int len = hi + 1 - lo;
+    if (len > cap) len = cap;
+    win.lo = lo;
+    win.len = len;
+    using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
+    const int full = (min(lo + len, n_cols & ~(PER16 - 1)) - lo) / PER16;   // whole 16-byte groups inside x
+    for (int g = tid; g < full; g += kBlock) {
+        *reinterpret_cast<v16*>(s_x + g * PER16) = *reinterpret_cast<const v16*>(x + lo + g * PER16);
+    }
+    for (int i = full * PER16 + tid; i < len; i += kBlock) s_x[i] = x[lo + i];
+    __syncthreads();
+    return win;
+}
+
+// One value of x: from the window when the column is inside it, else from global.
+template <typename val_t>
+__device__ __forceinline__ val_t window_gather(const XWindow<val_t>& win, const val_t* __restrict__ x,
+                                               int32_t col, bool needed) {
+    const unsigned rel = unsigned(col - win.lo);
+    const bool in = rel < unsigned(win.len);
+    val_t v = win.s_x[in ? rel : 0u];
+    if (needed && !in) v = x[col];
+    return v;
+}
+
+// Rows [chunk_begin, chunk_end) by this workgroup: T lanes per row, R rows per
+// vector in flight (R x the bytes in flight of one row: the loads of the R rows are
+// issued back to back before any is consumed), 4 nonzeros per lane per step.
+// All kBlock threads must call (wave-wide shuffles inside).
+template <int T, int R, typename off_t, typename val_t>
+__device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_end, off_t nnz,
+                                           const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
+                                           const val_t* __restrict__ Ax, const val_t* __restrict__ x,
+                                           val_t* __restrict__ y, const XWindow<val_t>& win) {
+    using v4 = typename Vec4<val_t>::type;
+    constexpr int VECS = kBlock / T;
+    const int lane = threadIdx.x & (T - 1);
+    const int vec = threadIdx.x / T;
+    for (int64_t base = chunk_begin; base < chunk_end; base += VECS * R) {
+        const int64_t row0 = base + int64_t(vec) * R;
+        off_t bound[R + 1];
+#pragma unroll
+        for (int r = 0; r <= R; ++r) {
+            const int64_t row = row0 + r;
+            bound[r] = Ap[row < chunk_end ? row : chunk_end];   // rows past the chunk become empty
+        }
+        off_t j[R];
+        val_t sum[R];
+        bool more = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            j[r] = (bound[r] & ~off_t(3)) + off_t(lane) * 4;
+            sum[r] = val_t(0);
+            more |= j[r] < bound[r + 1];
+        }
+        while (more) {
+            int4v c[R];
+            v4 a[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (j[r] < bound[r + 1]) {
+                    if (j[r] + 4 <= nnz) {
+                        c[r] = stream_load(reinterpret_cast<const int4v*>(Aj + j[r]));
+                        a[r] = stream_load(reinterpret_cast<const v4*>(Ax + j[r]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bool in = (j[r] + e) < nnz;
+                            c[r][e] = in ? Aj[j[r] + e] : 0;
+                            a[r][e] = in ? Ax[j[r] + e] : val_t(0);
+                        }
+                    }
+                } else {
+                    c[r] = int4v{0, 0, 0, 0};
+                    a[r] = v4{0, 0, 0, 0};
+                }
+            }
+            more = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const off_t k = j[r] + e;
+                    const bool valid = (k >= bound[r]) && (k < bound[r + 1]);
+                    const val_t xv = window_gather<val_t>(win, x, c[r][e], valid);
+                    sum[r] = valid ? (sum[r] + a[r][e] * xv) : sum[r];
+                }
+                j[r] += off_t(T) * 4;
+                more |= j[r] < bound[r + 1];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) sum[r] = vector_reduce<T, val_t>(sum[r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (row0 + r < chunk_end) y[row0 + r] = sum[r];
+            }
+        }
+    }
+}
+
+// Rows per workgroup chunk: ~32 K nonzeros (256 KB of fp32 stream) per chunk, a
+// multiple of the rows one pass of the workgroup covers.
+inline int64_t pick_rows_per_chunk(int64_t nnz, int64_t n_rows, int lanes_per_row, int rows_in_flight) {
+    const int64_t pass = int64_t(kBlock / lanes_per_row) * rows_in_flight;
+    const int64_t mean = n_rows > 0 ? (nnz + n_rows - 1) / n_rows : 1;
+    int64_t rows = 32768 / (mean > 0 ? mean : 1);
+    rows = (rows + pass - 1) / pass * pass;
+    if (rows < pass) rows = pass;
+    if (rows > 8192) rows = 8192 / pass * pass > 0 ? 8192 / pass * pass : pass;
+    return rows;
+}
+
+constexpr int kWindowBytes = 36 * 1024;   // LDS window of x per workgroup: 4 workgroups per CU
+
+}  // namespace mi355
