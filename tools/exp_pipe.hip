@@ -1,0 +1,159 @@
+// tools/exp_pipe.hip — scratch: what does software-pipelining the row-group loop buy,
+// and what do the sampled-window prologue / the fallback check cost?  Uses the
+// library's own headers.  (not part of the library)
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../spmv-samples_amd/csrc/xwindow.hpp"
+
+namespace mi355 { void set_error(const char*, ...) {} }
+using namespace mi355;
+
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(_e)); exit(1); } } while (0)
+
+__device__ __forceinline__ unsigned hash32(unsigned a) {
+    a ^= a >> 16; a *= 0x7feb352dU; a ^= a >> 15; a *= 0x846ca68bU; a ^= a >> 16; return a;
+}
+__global__ void gen_kernel(int n, int w, int* Ap, int* Aj, float* Ax, float* x) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < (long long)n * 32) {
+        const int r = int(k >> 5), i = int(k & 31);
+        const unsigned h = hash32(unsigned(k) * 2654435761u + 12345u);
+        const int stratum = 2 * w / 32;
+        long long c = (long long)r - w + (long long)i * stratum + (h % (unsigned)stratum);
+        if (c < 0) c = i;
+        if (c >= n) c = n - 32 + i;
+        Aj[k] = int(c);
+        Ax[k] = float(hash32(h) & 0xffff) / 32768.0f - 1.0f;
+    }
+    if (k <= n) Ap[k] = int(k * 32);
+    if (k < n) x[k] = float(hash32(unsigned(k) + 99u) & 0xffff) / 32768.0f - 1.0f;
+}
+
+// MODE 0: library body (sampled window, fallback)          = csr_vector_window_kernel
+// MODE 1: sampled window, pipelined row groups (loads one group ahead, Ap two ahead)
+// MODE 2: like 1, analytic window (no sample)   -> cost of the sample prologue
+// MODE 3: like 1, no fallback check             -> cost of the range check
+template <int T, int R, int MODE>
+__global__ __launch_bounds__(kBlock) void k_var(int n_rows, int n_cols, int nnz, const int* __restrict__ Ap,
+                                                const int* __restrict__ Aj, const float* __restrict__ Ax,
+                                                const float* __restrict__ x, float* __restrict__ y,
+                                                int rows_per_chunk, int w) {
+    __shared__ __attribute__((aligned(16))) float s_x[kWindowBytes / 4];
+    __shared__ int s_red[8];
+    const unsigned chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int64_t rb = int64_t(chunk) * rows_per_chunk;
+    const int64_t re = min(rb + rows_per_chunk, int64_t(n_rows));
+    XWindow<float> win;
+    if (MODE == 2) {
+        win.s_x = s_x;
+        win.lo = max(int(rb) - w, 0) & ~3;
+        win.len = min(min(int(re) + w, n_cols) - win.lo, kWindowBytes / 4);
+        for (int g = threadIdx.x; g < win.len / 4; g += kBlock) *(float4v*)&s_x[4 * g] = *(const float4v*)&x[win.lo + 4 * g];
+        __syncthreads();
+    } else {
+        win = stage_x_window<int, float>(rb, re, n_cols, Ap, Aj, x, s_x, kWindowBytes / 4, s_red);
+    }
+    if (MODE == 0) {
+        chunk_rows<T, R, int, float>(rb, re, nnz, Ap, Aj, Ax, x, y, win);
+        return;
+    }
+    constexpr int VECS = kBlock / T;
+    const int lane = threadIdx.x & (T - 1);
+    const int vec = threadIdx.x / T;
+    const int stride = VECS * R;
+    // pipeline registers
+    int bnd_n[R + 1];    // bounds of the NEXT group
+    int4v c_n[R]; float4v a_n[R]; int j_n[R];
+    auto load_bounds = [&](int64_t base, int* b) {
+#pragma unroll
+        for (int r = 0; r <= R; ++r) { const int64_t row = base + int64_t(vec) * R + r; b[r] = Ap[row < re ? row : re]; }
+    };
+    auto issue = [&](const int* b, int4v* c, float4v* a, int* j) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            j[r] = (b[r] & ~3) + lane * 4;
+            if (j[r] < b[r + 1] && j[r] + 4 <= nnz) {
+                c[r] = stream_load((const int4v*)(Aj + j[r]));
+                a[r] = stream_load((const float4v*)(Ax + j[r]));
+            } else { c[r] = int4v{0, 0, 0, 0}; a[r] = float4v{0, 0, 0, 0}; }
+        }
+    };
+    int bnd_c[R + 1];
+    load_bounds(rb, bnd_c);
+    int4v c_c[R]; float4v a_c[R]; int j_c[R];
+    issue(bnd_c, c_c, a_c, j_c);
+    load_bounds(rb + stride, bnd_n);
+    for (int64_t base = rb; base < re; base += stride) {
+        // issue next group's stream loads, and the bounds of the group after it
+        issue(bnd_n, c_n, a_n, j_n);
+        int bnd_nn[R + 1];
+        load_bounds(base + 2 * stride, bnd_nn);
+        const int64_t row0 = base + int64_t(vec) * R;
+        float sum[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            sum[r] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = j_c[r] + e;
+                const bool valid = (k >= bnd_c[r]) && (k < bnd_c[r + 1]);
+                float xv;
+                if (MODE == 3) { const unsigned rel = unsigned(c_c[r][e] - win.lo); xv = s_x[rel < unsigned(kWindowBytes / 4) ? rel : 0]; }
+                else xv = window_gather<float>(win, x, c_c[r][e], valid);
+                sum[r] = valid ? sum[r] + a_c[r][e] * xv : sum[r];
+            }
+            // (rows longer than 4T would continue here, unpipelined; none in this benchmark)
+            sum[r] = vector_reduce<T, float>(sum[r]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (row0 + r < re) y[row0 + r] = sum[r];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { c_c[r] = c_n[r]; a_c[r] = a_n[r]; j_c[r] = j_n[r]; }
+#pragma unroll
+        for (int r = 0; r <= R; ++r) { bnd_c[r] = bnd_n[r]; bnd_n[r] = bnd_nn[r]; }
+    }
+}
+
+static double checksum(const float* d, int n) {
+    std::vector<float> h(n);
+    CK(hipMemcpy(h.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
+    double s = 0; for (int i = 0; i < n; ++i) s += h[i];
+    return s;
+}
+template <typename F>
+static float time_it(F f, int iters = 30) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 5; ++i) f();
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) f();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipGetLastError());
+    return ms / iters;
+}
+
+int main() {
+    const int n = 1 << 22, w = 4096;
+    const long long nnz = (long long)n * 32;
+    int *Ap, *Aj; float *Ax, *x, *y;
+    CK(hipMalloc(&Ap, (n + 1) * 4)); CK(hipMalloc(&Aj, nnz * 4)); CK(hipMalloc(&Ax, nnz * 4));
+    CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&y, n * 4));
+    const double bytes = double(nnz) * 8 + (n + 1) * 4.0 + n * 4.0 + n * 4.0;
+    gen_kernel<<<(unsigned)((nnz + 255) / 256), 256>>>(n, w, Ap, Aj, Ax, x);
+    CK(hipDeviceSynchronize());
+#define RUN(T, R, MODE, RPC) { CK(hipMemset(y, 0, n * 4)); float ms = time_it([&] { k_var<T, R, MODE><<<n / RPC, 256>>>(n, n, (int)nnz, Ap, Aj, Ax, x, y, RPC, w); }); \
+    printf("T=%d R=%d mode=%d rows/chunk=%5d : %7.3f ms  %7.1f GB/s  sum=%.6e\n", T, R, MODE, RPC, ms, bytes / ms / 1e6, checksum(y, n)); }
+    for (int rep = 0; rep < 2; ++rep) {
+        RUN(8, 4, 0, 1024) RUN(8, 4, 1, 1024) RUN(8, 4, 2, 1024) RUN(8, 4, 3, 1024)
+        RUN(8, 4, 0, 2048) RUN(8, 4, 1, 2048) RUN(8, 4, 2, 2048)
+        RUN(8, 2, 1, 1024) RUN(8, 2, 1, 2048) RUN(8, 2, 0, 1024)
+        RUN(8, 4, 1, 512) RUN(8, 4, 0, 512)
+    }
+    return 0;
+}
