@@ -221,7 +221,7 @@ def main():
             "config": {"workload": "%s: %d rows/GPU x %d GPU, %d nnz/GPU, %s offsets, seeded"
                                    % (m.name, m.n_rows, world, m.nnz, "i32" if m.Ap.dtype == torch.int32 else "i64"),
                        "kind": kind, "lanes_per_row": info["lanes_per_row"], "grid_blocks": info["grid_blocks"],
-                       "kernels_per_step": info["n_kernels"], "reuse_structure": bool(args.reuse_structure),
+                       "kernels_per_step": info["n_kernels"], "x_window_elems": info["window_elems"], "reuse_structure": bool(args.reuse_structure),
                        "parallelism": "row-block x%d, x replicated, allgatherv(y)" % world if world > 1 else "single GPU"},
             "achieved_hbm_gbps": achieved,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -140,6 +140,10 @@ int mi355_spmv_plan_create(mi355_spmv_plan** out, int kind, int off_type, int va
     p.kind = kind; p.off_type = off_type; p.val_type = val_type; p.flags = flags;
     p.n_rows = n_rows; p.n_cols = n_cols; p.nnz = nnz; p.Ap = Ap; p.Aj = Aj;
     p.elems_per_lane = 4;
+    {
+        const int st = probe_structure(p);   // one tiny kernel + one 16-byte copy (synchronises)
+        if (st != MI355_SPMV_OK) { delete h; return st; }
+    }
     switch (kind) {
         case MI355_KIND_VECTOR: shape_vector(p); break;
         case MI355_KIND_MERGE:  shape_merge(p); break;
@@ -197,6 +201,7 @@ int mi355_spmv_plan_get_info(const mi355_spmv_plan* h, mi355_spmv_plan_info* inf
     info->rows_per_chunk = p.rows_per_chunk;
     info->scratch_bytes = (int64_t)p.scratch_bytes;
     info->n_kernels = p.n_kernels;
+    info->window_elems = p.window_elems;
     snprintf(info->main_kernel, sizeof(info->main_kernel), "%s", p.main_kernel);
     return MI355_SPMV_OK;
 }

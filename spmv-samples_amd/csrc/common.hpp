@@ -52,7 +52,12 @@ struct Plan {
     int64_t grid_blocks;
     // merge-path
     int64_t tile_items, n_tiles;
+    int64_t tiles_per_super, n_super;   // consecutive tiles one workgroup walks; number of such groups
     bool coords_valid;
+    // structure probe (plan creation): band of (column - row) seen on sampled rows
+    int64_t band_lo, band_hi;   // valid when probe_ok
+    bool probe_ok;
+    int window_elems;           // LDS window of x per workgroup, in elements; 0 = no window
     // dynamic rows
     int64_t rows_per_chunk;
     // scratch
@@ -60,8 +65,8 @@ struct Plan {
     size_t scratch_bytes;
     int32_t* tile_row;     // [n_tiles + 1]
     int64_t* tile_nnz;     // [n_tiles + 1]
-    int32_t* carry_row;    // [n_tiles]
-    void* carry_val;       // [n_tiles] of value type
+    int32_t* carry_row;    // [n_super]
+    void* carry_val;       // [n_super] of value type
     unsigned long long* counters;  // LIGHT: kXcds shards, one 128-B line each
     int n_kernels;
     char main_kernel[64];
@@ -75,6 +80,8 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
 template <typename off_t, typename val_t>
 int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s);
 
+int probe_structure(Plan& p);
+int pick_window_elems(const Plan& p, int64_t rows_per_workgroup);
 void shape_vector(Plan& p);
 void shape_merge(Plan& p);
 void shape_light(Plan& p);

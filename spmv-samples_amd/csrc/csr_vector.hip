@@ -23,15 +23,19 @@ namespace mi355 {
 template <int T, int R, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void csr_vector_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
-    const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, int32_t rows_per_chunk) {
-    __shared__ __attribute__((aligned(16))) val_t s_x[kWindowBytes / sizeof(val_t)];
+    const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, int32_t rows_per_chunk,
+    int32_t window_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window_cap values of x
+    val_t* s_x = reinterpret_cast<val_t*>(s_dyn);
     __shared__ int s_red[2 * (kBlock / kWave)];
+    __shared__ unsigned s_long_map[kMaxChunkRows / 32];
     const unsigned chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int64_t rb = int64_t(chunk) * rows_per_chunk;
     const int64_t re = min(rb + rows_per_chunk, int64_t(n_rows));
-    const XWindow<val_t> win = stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, s_x,
-                                                            int32_t(kWindowBytes / sizeof(val_t)), s_red);
-    chunk_rows<T, R, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win);
+    zero_long_map(s_long_map);           // ordered before chunk_rows by stage_x_window's barriers
+    const XWindow<val_t> win = stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, s_x, window_cap, s_red);
+    const ChunkScratch scr{s_long_map};
+    chunk_rows<T, R, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
 }
 
 template <int T, typename off_t, typename val_t>
@@ -64,6 +68,7 @@ void shape_vector(Plan& p) {
     p.grid_blocks = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
     if (p.grid_blocks < 1) p.grid_blocks = 1;
     p.n_tiles = p.grid_blocks;
+    p.window_elems = pick_window_elems(p, p.rows_per_chunk);
     p.n_kernels = 1;
     snprintf(p.main_kernel, sizeof(p.main_kernel), "csr_vector_window_kernel");
 }
@@ -76,8 +81,9 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
     const off_t nnz = (off_t)p.nnz;
 #define MI355_VEC_CASE(TT)                                                                             \
     case TT:                                                                                           \
-        hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, off_t, val_t>), grid, block, 0, s, p.n_rows, \
-                           p.n_cols, nnz, Ap, p.Aj, Ax, x, y, (int32_t)p.rows_per_chunk);              \
+        hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, off_t, val_t>), grid, block,               \
+                           size_t(p.window_elems) * sizeof(val_t), s, p.n_rows, p.n_cols, nnz, Ap,     \
+                           p.Aj, Ax, x, y, (int32_t)p.rows_per_chunk, (int32_t)p.window_elems);        \
         break;
     switch (p.lanes_per_row) {
         MI355_VEC_CASE(2)

@@ -48,10 +48,13 @@ template <int T, int R, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
-    unsigned long long* __restrict__ counters, int32_t rows_per_chunk) {
-    __shared__ __attribute__((aligned(16))) val_t s_x[kWindowBytes / sizeof(val_t)];
+    unsigned long long* __restrict__ counters, int32_t rows_per_chunk, int32_t window_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window_cap values of x
+    val_t* s_x = reinterpret_cast<val_t*>(s_dyn);
     __shared__ int s_red[2 * (kBlock / kWave)];
+    __shared__ unsigned s_long_map[kMaxChunkRows / 32];
     __shared__ unsigned long long s_got;
+    const ChunkScratch scr{s_long_map};
     const int home = blockIdx.x % kXcds;
     for (int visit = 0; visit < kXcds; ++visit) {
         const int shard = (home + visit) % kXcds;
@@ -61,14 +64,15 @@ __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
             if (threadIdx.x == 0) {
                 s_got = atomicAdd(&counters[shard * kCounterStride], (unsigned long long)rows_per_chunk);
             }
+            zero_long_map(s_long_map);
             __syncthreads();
             const int64_t chunk_begin = shard_begin + int64_t(wave_broadcast_u64(s_got));
             if (chunk_begin >= shard_end) break;  // uniform over the workgroup
             const int64_t chunk_end = min(chunk_begin + rows_per_chunk, shard_end);
             // (stage_x_window's barriers also order this read of s_got before the next write)
             const XWindow<val_t> win = stage_x_window<off_t, val_t>(
-                chunk_begin, chunk_end, n_cols, Ap, Aj, x, s_x, int32_t(kWindowBytes / sizeof(val_t)), s_red);
-            chunk_rows<T, R, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win);
+                chunk_begin, chunk_end, n_cols, Ap, Aj, x, s_x, window_cap, s_red);
+            chunk_rows<T, R, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
             __syncthreads();  // every wave is done with the window before it is refilled
         }
         __syncthreads();      // s_got read by all before the next shard's dequeue overwrites it
@@ -128,9 +132,12 @@ void shape_light(Plan& p) {
     if (chunk < pass) chunk = pass;
     p.rows_per_chunk = chunk;
     p.n_tiles = (int64_t(p.n_rows) + chunk - 1) / chunk;
-    // persistent grid: 4 workgroups per CU (LDS window 36 KB each), fewer for small inputs
+    p.window_elems = pick_window_elems(p, chunk);
+    // persistent grid: 4 workgroups per CU with the 36 KB window, 5 without (VGPR-bound),
+    // fewer for small inputs
     int64_t blocks = p.n_tiles;
-    if (blocks > int64_t(kCus) * 4) blocks = int64_t(kCus) * 4;
+    const int64_t resident = int64_t(kCus) * (p.window_elems ? 4 : 5);
+    if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
     p.grid_blocks = blocks;
     p.n_kernels = 1;
@@ -146,8 +153,9 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
     const int32_t chunk = (int32_t)p.rows_per_chunk;
 #define MI355_LIGHT_CASE(TT)                                                                             \
     case TT:                                                                                             \
-        hipLaunchKernelGGL((light_rows_window_kernel<TT, R, off_t, val_t>), grid, block, 0, s, p.n_rows,  \
-                           p.n_cols, nnz, Ap, p.Aj, Ax, x, y, p.counters, chunk);                        \
+        hipLaunchKernelGGL((light_rows_window_kernel<TT, R, off_t, val_t>), grid, block,                 \
+                           size_t(p.window_elems) * sizeof(val_t), s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, \
+                           Ax, x, y, p.counters, chunk, (int32_t)p.window_elems);                        \
         break;
     switch (p.lanes_per_row) {
         MI355_LIGHT_CASE(2)

@@ -11,9 +11,16 @@
 // variant that accepts 64-bit offsets): both offset widths are instantiated here.
 //
 // The decomposition is the reference's: the merge of the row-end offsets
-// Ap[1..n_rows] with the counting sequence 0..nnz-1 is cut into tiles of
-// TILE = 256 * IPT items; a tile owns the rows that END inside it and the
-// nonzeros inside it, whatever the row lengths.  What is rebuilt for MI355X:
+// Ap[1..n_rows] with the counting sequence 0..nnz-1 is cut into tiles of equal item
+// count; a tile owns the rows that END inside it and the nonzeros inside it,
+// whatever the row lengths.  What is rebuilt for MI355X:
+//  * a workgroup walks a RUN of consecutive tiles (a "super-tile", ~32 K items) so
+//    that (a) the window of x those tiles touch is staged through LDS once
+//    (xwindow.hpp — the plain global gather, not the Aj/Ax stream, bounds SpMV on
+//    this chip), (b) the next tile's Aj/Ax are already in flight in registers while
+//    the current tile is walked, (c) the partial sum of a row that crosses tiles is
+//    carried in a register instead of through memory: only one carry per
+//    super-tile reaches the fix-up kernel;
 //  * nonzeros are streamed with 16-byte-per-lane loads from the tile start
 //    rounded down to a multiple of 4 (the reference reads 4 bytes per lane,
 //    strided by the block, agent_spmv_orig.cuh:474-506);
@@ -25,23 +32,29 @@
 //  * the reference's cub::BlockScan of (key, value) pairs with ReduceByKeyOp
 //    (agent_spmv_orig.cuh:616-629) becomes a flag-segmented wave64 scan
 //    (six __shfl_up steps) plus a 4-entry cross-wave pass, written here;
-//  * rows finished by a thread go straight to an LDS partial array during the
-//    walk (no per-item key/value register arrays), then to y with coalesced stores;
+//  * a row closed inside one thread is stored to y straight from the walk (no
+//    per-item key/value register arrays, no LDS scatter pass);
 //  * the fix-up is deterministic: one thread per distinct carried row sums that
-//    row's tile carries in tile order and adds once, instead of float atomics
+//    row's carries in order and adds once, instead of float atomics
 //    (agent_segment_fixup.cuh:228-271), so results do not change
 //    from run to run;
-//  * tile ids are remapped so each XCD walks a contiguous range of the matrix.
+//  * super-tile ids are remapped so each XCD walks a contiguous range of the matrix.
 //
 // n_cols == 1 (the reference's special kernel, dispatch_spmv_orig.cuh:68-96,
 // :572-597) needs no special case here.
 
 #include <climits>
+#include <cstdlib>
 
 #include "common.hpp"
 #include "row_dot.hpp"
+#include "xwindow.hpp"
 
 namespace mi355 {
+
+// merge items per thread (IPT) is 8 or 16; a tile has kBlock * IPT - 4 items so that
+// (tile nnz + 3) / 4 <= kBlock * IPT / 4 sixteen-byte groups, IPT / 4 per thread
+constexpr int kMergeSuperItems = 32768;                   // items one workgroup walks at most
 
 // ---- K6: tile start coordinates ------------------------------------------------
 template <typename off_t>
@@ -64,162 +77,221 @@ __global__ __launch_bounds__(kBlock) void merge_search_kernel(
     tile_nnz[t] = diag - lo;
 }
 
-// ---- K7: one tile per workgroup ---------------------------------------------------
+// ---- K7: one run of consecutive tiles per workgroup ---------------------------------
 template <int IPT, bool VEC, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
-    int32_t n_rows, int64_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
+    int32_t n_rows, int32_t n_cols, int64_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
     const int32_t* __restrict__ tile_row, const int64_t* __restrict__ tile_nnz,
-    int32_t* __restrict__ carry_row, val_t* __restrict__ carry_val) {
-    constexpr int TILE = kBlock * IPT;
+    int32_t* __restrict__ carry_row, val_t* __restrict__ carry_val, int64_t n_tiles, int32_t tiles_per_super,
+    int32_t window_cap) {
+    constexpr int G = IPT / 4;
     using v4 = typename Vec4<val_t>::type;
-    __shared__ __attribute__((aligned(32))) val_t s_nz[TILE + 4];  // products, index = nnz - (y0 & ~3)
-    __shared__ int s_re[TILE + 1];                                 // tile-relative row ends
-    __shared__ val_t s_part[TILE];                                 // sums of the rows ending here
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window_cap values of x
+    val_t* s_x = reinterpret_cast<val_t*>(s_dyn);
+    __shared__ __attribute__((aligned(32))) val_t s_nz[kBlock * IPT];   // products, index = nnz - (y0 & ~3)
+    __shared__ int s_re[kBlock * IPT + 1];                               // tile-relative row ends
     __shared__ val_t s_wave_sum[kBlock / kWave];
     __shared__ int s_wave_flag[kBlock / kWave];
+    __shared__ val_t s_carry;
+    __shared__ int s_red[2];
 
-    const unsigned t = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const unsigned sup = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
     const int lane64 = tid & (kWave - 1);
     const int wave = tid / kWave;
+    const int64_t first = int64_t(sup) * tiles_per_super;
+    const int64_t last = min(first + tiles_per_super, n_tiles);
 
-    const int x0 = tile_row[t], x1 = tile_row[t + 1];
-    const int64_t y0 = tile_nnz[t], y1 = tile_nnz[t + 1];
-    const int tr = x1 - x0;            // rows that end in this tile
-    const int tn = int(y1 - y0);       // nonzeros in this tile
-    const int shift = VEC ? int(y0 & 3) : 0;
-    const int64_t yb = y0 - shift;     // 16-byte aligned start of the stream
+    // the window of x for all rows this run touches (incl. the row left open at its end)
+    const int64_t row_lo = tile_row[first];
+    const int64_t row_hi = min(int64_t(tile_row[last]) + 1, int64_t(n_rows));
+    const XWindow<val_t> win =
+        stage_x_window<off_t, val_t>(row_lo, row_hi, n_cols, Ap, Aj, x, s_x, window_cap, s_red);
 
-    // (1) products a*x for the tile's nonzeros, 4 per lane per load
-    if constexpr (!VEC) {
-        // Aj / Ax not 16-byte aligned (an offset view): 4-byte-per-lane form
-        for (int i = tid; i < tn; i += kBlock) s_nz[i] = Ax[y0 + i] * x[Aj[y0 + i]];
-    } else
-    for (int g = tid; 4 * g < tn + shift; g += kBlock) {
-        const int64_t j = yb + 4 * int64_t(g);
-        int4v c;
-        v4 a;
-        if (j + 4 <= nnz) {
-            c = stream_load(reinterpret_cast<const int4v*>(Aj + j));
-            a = stream_load(reinterpret_cast<const v4*>(Ax + j));
-        } else {
+    int x0 = tile_row[first], x1 = tile_row[first + 1];
+    int64_t y0 = tile_nnz[first], y1 = tile_nnz[first + 1];
+
+    // registers holding the Aj/Ax groups of the tile about to be processed
+    int4v c[G];
+    v4 a[G];
+    auto issue = [&](int64_t ya, int64_t ye) {
+        const int64_t base = ya & ~int64_t(3);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool in = (j + e) < nnz;
-                c[e] = in ? Aj[j + e] : 0;
-                a[e] = in ? Ax[j + e] : val_t(0);
-            }
-        }
-        v4 p;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) p[e] = a[e] * x[c[e]];
-        *reinterpret_cast<v4*>(&s_nz[4 * g]) = p;
-    }
-    // (2) row ends, relative to y0; the row still open at the tile end never ends here
-    for (int i = tid; i <= tr; i += kBlock) {
-        s_re[i] = (i < tr) ? int(int64_t(Ap[int64_t(x0) + i + 1]) - y0) : INT_MAX;
-    }
-    __syncthreads();
-
-    // (3) this thread's piece of the merge path: items [d0, d1) of the tile
-    const int items = tr + tn;
-    const int d0 = min(tid * IPT, items);
-    const int d1 = min(d0 + IPT, items);
-    int lo = max(d0 - tn, 0), hi = min(d0, tr);
-    while (lo < hi) {
-        const int p = (lo + hi) >> 1;
-        if (s_re[p] <= d0 - p - 1) lo = p + 1;
-        else hi = p;
-    }
-    int cx = lo, cy = d0 - lo;
-
-    // (4) walk: a nonzero extends the running row sum, a row end closes it
-    val_t run = val_t(0), first_val = val_t(0);
-    int first_end = -1;
-    int re = s_re[cx];
-    const int cnt = d1 - d0;
-#pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-        if (k < cnt) {
-            if (cy < re) {
-                run += s_nz[cy + shift];
-                ++cy;
+        for (int g = 0; g < G; ++g) {
+            const int64_t j = base + 4 * int64_t(tid + g * kBlock);
+            if (j < ye) {
+                load_group<int64_t, val_t>(j, nnz, Aj, Ax, c[g], a[g]);
             } else {
-                if (first_end < 0) {
-                    first_end = cx;      // may continue a row opened by earlier threads
-                    first_val = run;
-                } else {
-                    s_part[cx] = run;    // opened and closed inside this thread
-                }
-                run = val_t(0);
-                ++cx;
-                re = s_re[cx];
+                c[g] = int4v{0, 0, 0, 0};
+                a[g] = v4{0, 0, 0, 0};
             }
         }
-    }
+    };
+    if constexpr (VEC) issue(y0, y1);
 
-    // (5) carry-in = sum of the open-row tails of the preceding threads back to
-    //     the last thread that closed a row: a flag-segmented inclusive scan
-    val_t sv = run;
-    int sf = first_end >= 0 ? 1 : 0;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const val_t ov = __shfl_up(sv, d, kWave);
-        const int of = __shfl_up(sf, d, kWave);
-        if (lane64 >= d) {
-            if (!sf) sv = ov + sv;
-            sf |= of;
+    val_t block_carry = val_t(0);   // sum so far of the row left open by the previous tile of this run
+    for (int64_t t = first; t < last; ++t) {
+        int x2 = x1;
+        int64_t y2 = y1;
+        if (t + 1 < last) {
+            x2 = tile_row[t + 2];
+            y2 = tile_nnz[t + 2];
         }
-    }
-    if (lane64 == kWave - 1) {
-        s_wave_sum[wave] = sv;
-        s_wave_flag[wave] = sf;
-    }
-    __syncthreads();
-    val_t prefix = val_t(0);  // block-inclusive value at the end of the previous wave
-    for (int w = 0; w < wave; ++w) prefix = s_wave_flag[w] ? s_wave_sum[w] : prefix + s_wave_sum[w];
-    const val_t incl = sf ? sv : prefix + sv;
-    val_t carry_in = __shfl_up(incl, 1, kWave);
-    if (lane64 == 0) carry_in = prefix;
+        const int tr = x1 - x0;            // rows that end in this tile
+        const int tn = int(y1 - y0);       // nonzeros in this tile
+        const int shift = VEC ? int(y0 & 3) : 0;
 
-    if (first_end >= 0) s_part[first_end] = carry_in + first_val;
-    if (tid == kBlock - 1) {
-        // the row still open at the end of the tile: x1 (== n_rows means none)
-        carry_row[t] = x1;
-        carry_val[t] = incl;
-    }
-    __syncthreads();
+        // (1) products a*x for the tile's nonzeros
+        if constexpr (VEC) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int rel = 4 * (tid + g * kBlock) - shift;   // tile-relative index of element 0
+                v4 p;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool needed = (rel + e >= 0) && (rel + e < tn);
+                    p[e] = a[g][e] * window_gather<val_t>(win, x, c[g][e], needed);
+                }
+                *reinterpret_cast<v4*>(&s_nz[4 * (tid + g * kBlock)]) = p;
+            }
+            // the next tile's stream goes in flight now and lands while this tile is walked
+            if (t + 1 < last) issue(y1, y2);
+        } else {
+            // Aj / Ax not 16-byte aligned (an offset view): 4-byte-per-lane form
+            for (int i = tid; i < tn; i += kBlock) {
+                const int32_t col = Aj[y0 + i];
+                s_nz[i] = Ax[y0 + i] * window_gather<val_t>(win, x, col, true);
+            }
+        }
+        // (2) row ends, relative to y0; the row still open at the tile end never ends here
+        for (int i = tid; i <= tr; i += kBlock) {
+            s_re[i] = (i < tr) ? int(int64_t(Ap[int64_t(x0) + i + 1]) - y0) : INT_MAX;
+        }
+        __syncthreads();
 
-    // (6) rows that ended in this tile, coalesced
-    for (int i = tid; i < tr; i += kBlock) y[int64_t(x0) + i] = s_part[i];
+        // (3) this thread's piece of the merge path: items [d0, d1) of the tile
+        const int items = tr + tn;
+        const int d0 = min(tid * IPT, items);
+        const int d1 = min(d0 + IPT, items);
+        int lo = max(d0 - tn, 0), hi = min(d0, tr);
+        while (lo < hi) {
+            const int p = (lo + hi) >> 1;
+            if (s_re[p] <= d0 - p - 1) lo = p + 1;
+            else hi = p;
+        }
+        int cx = lo, cy = d0 - lo;
+
+        // (4) walk: a nonzero extends the running row sum, a row end closes it
+        val_t run = val_t(0), first_val = val_t(0);
+        int first_end = -1;
+        int re = s_re[cx];
+        const int cnt = d1 - d0;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            if (k < cnt) {
+                if (cy < re) {
+                    run += s_nz[cy + shift];
+                    ++cy;
+                } else {
+                    if (first_end < 0) {
+                        first_end = cx;                   // may continue a row opened by earlier threads
+                        first_val = run;
+                    } else {
+                        y[int64_t(x0) + cx] = run;        // opened and closed inside this thread
+                    }
+                    run = val_t(0);
+                    ++cx;
+                    re = s_re[cx];
+                }
+            }
+        }
+
+        // (5) carry-in = sum of the open-row tails of the preceding threads back to the
+        //     last thread that closed a row (or the previous tile's carry): a
+        //     flag-segmented inclusive scan
+        val_t sv = run;
+        int sf = first_end >= 0 ? 1 : 0;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const val_t ov = __shfl_up(sv, d, kWave);
+            const int of = __shfl_up(sf, d, kWave);
+            if (lane64 >= d) {
+                if (!sf) sv = ov + sv;
+                sf |= of;
+            }
+        }
+        if (lane64 == kWave - 1) {
+            s_wave_sum[wave] = sv;
+            s_wave_flag[wave] = sf;
+        }
+        __syncthreads();
+        val_t prefix = block_carry;  // block-inclusive value at the end of the previous wave
+        for (int w = 0; w < wave; ++w) prefix = s_wave_flag[w] ? s_wave_sum[w] : prefix + s_wave_sum[w];
+        const val_t incl = sf ? sv : prefix + sv;
+        val_t carry_in = __shfl_up(incl, 1, kWave);
+        if (lane64 == 0) carry_in = prefix;
+        if (first_end >= 0) y[int64_t(x0) + first_end] = carry_in + first_val;
+        if (tid == kBlock - 1) s_carry = incl;   // the row still open at the end of the tile
+        __syncthreads();                          // also frees s_nz / s_re / s_wave_* for the next tile
+        block_carry = s_carry;
+        x0 = x1; y0 = y1;
+        x1 = x2; y1 = y2;
+    }
+    if (tid == 0) {
+        // the row still open at the end of the run: x0 now holds tile_row[last] (== n_rows: none)
+        carry_row[sup] = x0;
+        carry_val[sup] = block_carry;
+    }
 }
 
-// ---- K8: add the tile carries of rows that straddle tiles ---------------------------
+// ---- K8: add the carries of rows that straddle runs ------------------------------------
 template <typename val_t>
 __global__ __launch_bounds__(kBlock) void merge_fixup_kernel(
-    int64_t n_tiles, int32_t n_rows, const int32_t* __restrict__ carry_row,
+    int64_t n_carries, int32_t n_rows, const int32_t* __restrict__ carry_row,
     const val_t* __restrict__ carry_val, val_t* __restrict__ y) {
     const int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (t >= n_tiles) return;
+    if (t >= n_carries) return;
     const int32_t r = carry_row[t];
     if (r >= n_rows) return;
-    if (t > 0 && carry_row[t - 1] == r) return;  // not the first tile carrying row r
+    if (t > 0 && carry_row[t - 1] == r) return;  // not the first run carrying row r
     val_t s = carry_val[t];
-    for (int64_t u = t + 1; u < n_tiles && carry_row[u] == r; ++u) s += carry_val[u];
+    for (int64_t u = t + 1; u < n_carries && carry_row[u] == r; ++u) s += carry_val[u];
     y[r] += s;
 }
 
 // ---- host side -----------------------------------------------------------------------
-constexpr int kMergeIpt = 8;
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
 
 void shape_merge(Plan& p) {
+    // tuning knobs (defaults are the measured best): MI355_MERGE_IPT = 8|16 items per
+    // thread, MI355_MERGE_TPS = tiles per run (and MI355_SPMV_WINDOW = 0|1, analyze.hip)
+    const int ipt = env_int("MI355_MERGE_IPT", 8) == 16 ? 16 : 8;
     p.lanes_per_row = 0;
-    p.tile_items = int64_t(kBlock) * kMergeIpt;
+    p.elems_per_lane = ipt;            // reported as items per thread for this kind
+    p.tile_items = int64_t(kBlock) * ipt - 4;
     const int64_t items = int64_t(p.n_rows) + p.nnz;
     p.n_tiles = (items + p.tile_items - 1) / p.tile_items;
-    p.grid_blocks = p.n_tiles;
-    p.n_kernels = p.n_tiles > 1 ? 3 : 2;
+    // runs of up to ~32 K items, but at least ~4 runs per CU when the matrix allows
+    int64_t tps = p.n_tiles / (int64_t(kCus) * 4);
+    const int64_t cap = kMergeSuperItems / p.tile_items;
+    if (tps > cap) tps = cap;
+    tps = env_int("MI355_MERGE_TPS", int(tps));
+    if (tps < 1) tps = 1;
+    p.tiles_per_super = tps;
+    p.n_super = (p.n_tiles + tps - 1) / tps;
+    p.grid_blocks = p.n_super;
+    // a window of x only pays when a run is long enough to amortise staging it, and
+    // when the band the probe saw (plus the rows of a run) fits
+    {
+        const int64_t mean1 = 1 + (p.n_rows > 0 ? p.nnz / p.n_rows : 0);
+        const int64_t rows_per_run = tps * p.tile_items / mean1 + 1;
+        p.window_elems = (tps * p.tile_items >= 8192) ? pick_window_elems(p, rows_per_run) : 0;
+    }
+    p.n_kernels = p.n_super > 1 ? 3 : 2;
     p.coords_valid = false;
     snprintf(p.main_kernel, sizeof(p.main_kernel), "merge_tile_kernel");
 }
@@ -227,7 +299,8 @@ void shape_merge(Plan& p) {
 template <typename off_t, typename val_t>
 int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s) {
     if (p.n_rows == 0 || p.n_tiles == 0) return MI355_SPMV_OK;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax)) & 15u) == 0;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
+                           reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
     const bool reuse = (p.flags & MI355_PLAN_REUSE_STRUCTURE) && p.coords_valid;
     if (!reuse) {
         const unsigned g = unsigned((p.n_tiles + 1 + kBlock - 1) / kBlock);
@@ -236,19 +309,23 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
         MI355_HIP_TRY(hipGetLastError());
         p.coords_valid = true;
     }
-    if (aligned) {
-        hipLaunchKernelGGL((merge_tile_kernel<kMergeIpt, true, off_t, val_t>), dim3((unsigned)p.n_tiles),
-                           dim3(kBlock), 0, s, p.n_rows, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz,
-                           p.carry_row, static_cast<val_t*>(p.carry_val));
+    const int32_t cap = aligned ? (int32_t)p.window_elems : 0;
+    const size_t dyn = size_t(cap) * sizeof(val_t);
+    const dim3 grid((unsigned)p.n_super), block(kBlock);
+#define MI355_MERGE_LAUNCH(IPT_, VEC_)                                                                         \
+    hipLaunchKernelGGL((merge_tile_kernel<IPT_, VEC_, off_t, val_t>), grid, block, dyn, s, p.n_rows, p.n_cols,  \
+                       p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz, p.carry_row,                        \
+                       static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super, cap)
+    if (p.elems_per_lane == 16) {
+        if (aligned) MI355_MERGE_LAUNCH(16, true); else MI355_MERGE_LAUNCH(16, false);
     } else {
-        hipLaunchKernelGGL((merge_tile_kernel<kMergeIpt, false, off_t, val_t>), dim3((unsigned)p.n_tiles),
-                           dim3(kBlock), 0, s, p.n_rows, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz,
-                           p.carry_row, static_cast<val_t*>(p.carry_val));
+        if (aligned) MI355_MERGE_LAUNCH(8, true); else MI355_MERGE_LAUNCH(8, false);
     }
+#undef MI355_MERGE_LAUNCH
     MI355_HIP_TRY(hipGetLastError());
-    if (p.n_tiles > 1) {
-        const unsigned g = unsigned((p.n_tiles + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL((merge_fixup_kernel<val_t>), dim3(g), dim3(kBlock), 0, s, p.n_tiles, p.n_rows,
+    if (p.n_super > 1) {
+        const unsigned g = unsigned((p.n_super + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL((merge_fixup_kernel<val_t>), dim3(g), dim3(kBlock), 0, s, p.n_super, p.n_rows,
                            p.carry_row, static_cast<const val_t*>(p.carry_val), y);
         MI355_HIP_TRY(hipGetLastError());
     }

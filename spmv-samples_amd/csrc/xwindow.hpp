@@ -97,6 +97,12 @@ __device__ __forceinline__ XWindow<val_t> stage_x_window(int64_t rb, int64_t re,
     // The samples may miss the extremes: widen the sampled span by an eighth (+64) on
     // each side; if that exceeds the capacity, centre the window on the span.
     const int span = hi - lo + 1;
+    if (cap <= 0 || span / 16 > cap) {   // columns scattered far beyond what LDS can hold: not worth a window
+        win.lo = 0;
+        win.len = 0;
+        __syncthreads();
+        return win;
+    }
     int len = span + 2 * (span / 8 + 64);
     if (len > cap) len = cap;
     if (len > n_cols) len = n_cols;
@@ -129,17 +135,55 @@ __device__ __forceinline__ val_t window_gather(const XWindow<val_t>& win, const 
     return v;
 }
 
+// LDS scratch of one workgroup for chunk_rows.
+constexpr int kMaxChunkRows = 8192;   // upper bound of rows per chunk (pick_rows_per_chunk)
+constexpr int kLongSteps = 16;        // a row is "long" beyond this many steps of its T-lane vector
+struct ChunkScratch {
+    // one bit per row of the chunk: set = long row, summed in the second pass.
+    // Zeroed by the caller (zero_long_map) before the barrier that precedes chunk_rows.
+    unsigned* long_map;   // [kMaxChunkRows / 32]
+};
+__device__ __forceinline__ void zero_long_map(unsigned* long_map) {
+    for (int i = threadIdx.x; i < kMaxChunkRows / 32; i += kBlock) long_map[i] = 0u;
+}
+
+// One step of 4 nonzeros of one lane: Aj/Ax group at j (16-byte aligned element index).
+template <typename off_t, typename val_t>
+__device__ __forceinline__ void load_group(off_t j, off_t nnz, const int32_t* __restrict__ Aj,
+                                           const val_t* __restrict__ Ax, int4v& c,
+                                           typename Vec4<val_t>::type& a) {
+    using v4 = typename Vec4<val_t>::type;
+    if (j + 4 <= nnz) {
+        c = stream_load(reinterpret_cast<const int4v*>(Aj + j));
+        a = stream_load(reinterpret_cast<const v4*>(Ax + j));
+    } else {   // last, partial group of the arrays: never read past nnz
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool in = (j + e) < nnz;
+            c[e] = in ? Aj[j + e] : 0;
+            a[e] = in ? Ax[j + e] : val_t(0);
+        }
+    }
+}
+
 // Rows [chunk_begin, chunk_end) by this workgroup: T lanes per row, R rows per
 // vector in flight (R x the bytes in flight of one row: the loads of the R rows are
 // issued back to back before any is consumed), 4 nonzeros per lane per step.
-// All kBlock threads must call (wave-wide shuffles inside).
+// A row longer than kLongSteps steps is not walked by its T lanes (a power-law hub
+// row would serialise the whole chunk behind one vector — the weakness of the
+// reference's CSR-vector and LightSpMV kernels on such inputs): its bit is set in an
+// LDS bitmap and a second pass sums every marked row with a whole 64-lane wave,
+// 512 nonzeros per step, the four waves taking marked rows in turn.
+// All kBlock threads must call (wave-wide shuffles and one barrier inside).
 template <int T, int R, typename off_t, typename val_t>
 __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_end, off_t nnz,
                                            const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
                                            const val_t* __restrict__ Ax, const val_t* __restrict__ x,
-                                           val_t* __restrict__ y, const XWindow<val_t>& win) {
+                                           val_t* __restrict__ y, const XWindow<val_t>& win,
+                                           const ChunkScratch& scr) {
     using v4 = typename Vec4<val_t>::type;
     constexpr int VECS = kBlock / T;
+    constexpr off_t LONG = off_t(T) * 4 * kLongSteps;
     const int lane = threadIdx.x & (T - 1);
     const int vec = threadIdx.x / T;
     for (int64_t base = chunk_begin; base < chunk_end; base += VECS * R) {
@@ -152,10 +196,16 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
         }
         off_t j[R];
         val_t sum[R];
+        bool deferred[R];
         bool more = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            j[r] = (bound[r] & ~off_t(3)) + off_t(lane) * 4;
+            deferred[r] = (bound[r + 1] - bound[r]) > LONG;     // uniform over the T lanes of the vector
+            if (deferred[r] && lane == 0) {
+                const unsigned rel = unsigned(row0 + r - chunk_begin);
+                atomicOr(&scr.long_map[rel >> 5], 1u << (rel & 31));
+            }
+            j[r] = deferred[r] ? bound[r + 1] : (bound[r] & ~off_t(3)) + off_t(lane) * 4;
             sum[r] = val_t(0);
             more |= j[r] < bound[r + 1];
         }
@@ -165,17 +215,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (j[r] < bound[r + 1]) {
-                    if (j[r] + 4 <= nnz) {
-                        c[r] = stream_load(reinterpret_cast<const int4v*>(Aj + j[r]));
-                        a[r] = stream_load(reinterpret_cast<const v4*>(Ax + j[r]));
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const bool in = (j[r] + e) < nnz;
-                            c[r][e] = in ? Aj[j[r] + e] : 0;
-                            a[r][e] = in ? Ax[j[r] + e] : val_t(0);
-                        }
-                    }
+                    load_group<off_t, val_t>(j[r], nnz, Aj, Ax, c[r], a[r]);
                 } else {
                     c[r] = int4v{0, 0, 0, 0};
                     a[r] = v4{0, 0, 0, 0};
@@ -200,8 +240,48 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
         if (lane == 0) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (row0 + r < chunk_end) y[row0 + r] = sum[r];
+                if (row0 + r < chunk_end && !deferred[r]) y[row0 + r] = sum[r];
             }
+        }
+    }
+
+    // second pass: every marked row by one whole wave (64 lanes x 4 nonzeros x 2 groups per step)
+    __syncthreads();
+    const int lane64 = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int words = int((chunk_end - chunk_begin + 31) >> 5);
+    int turn = 0;                                   // marked rows are dealt to the waves in turn
+    for (int w = 0; w < words; ++w) {
+        unsigned bits = scr.long_map[w];            // same value in every lane
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            if ((turn++ & (kBlock / kWave - 1)) != wave) continue;   // wave-uniform
+            const int64_t row = chunk_begin + (int64_t(w) << 5) + b;
+            const off_t start = Ap[row], end = Ap[row + 1];
+            val_t sum = val_t(0);
+            for (off_t j = (start & ~off_t(3)) + off_t(lane64) * 4; j < end; j += off_t(kWave) * 8) {
+                int4v c0, c1;
+                v4 a0, a1;
+                const off_t j1 = j + off_t(kWave) * 4;
+                load_group<off_t, val_t>(j, nnz, Aj, Ax, c0, a0);
+                if (j1 < end) load_group<off_t, val_t>(j1, nnz, Aj, Ax, c1, a1);
+                else { c1 = int4v{0, 0, 0, 0}; a1 = v4{0, 0, 0, 0}; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool valid = (j + e >= start) && (j + e < end);
+                    const val_t xv = window_gather<val_t>(win, x, c0[e], valid);
+                    sum = valid ? (sum + a0[e] * xv) : sum;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool valid = (j1 + e < end);
+                    const val_t xv = window_gather<val_t>(win, x, c1[e], valid);
+                    sum = valid ? (sum + a1[e] * xv) : sum;
+                }
+            }
+            sum = vector_reduce<kWave, val_t>(sum);
+            if (lane64 == 0) y[row] = sum;
         }
     }
 }
@@ -212,9 +292,12 @@ inline int64_t pick_rows_per_chunk(int64_t nnz, int64_t n_rows, int lanes_per_ro
     const int64_t pass = int64_t(kBlock / lanes_per_row) * rows_in_flight;
     const int64_t mean = n_rows > 0 ? (nnz + n_rows - 1) / n_rows : 1;
     int64_t rows = 32768 / (mean > 0 ? mean : 1);
+    // small matrices: prefer >= 4 chunks per CU over long chunks
+    const int64_t fill = (n_rows + int64_t(kCus) * 4 - 1) / (int64_t(kCus) * 4);
+    if (rows > fill) rows = fill;
     rows = (rows + pass - 1) / pass * pass;
     if (rows < pass) rows = pass;
-    if (rows > 8192) rows = 8192 / pass * pass > 0 ? 8192 / pass * pass : pass;
+    if (rows > kMaxChunkRows) rows = kMaxChunkRows / pass * pass > 0 ? kMaxChunkRows / pass * pass : pass;
     return rows;
 }
 

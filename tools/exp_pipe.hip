@@ -58,7 +58,11 @@ __global__ __launch_bounds__(kBlock) void k_var(int n_rows, int n_cols, int nnz,
         win = stage_x_window<int, float>(rb, re, n_cols, Ap, Aj, x, s_x, kWindowBytes / 4, s_red);
     }
     if (MODE == 0) {
-        chunk_rows<T, R, int, float>(rb, re, nnz, Ap, Aj, Ax, x, y, win);
+        __shared__ unsigned s_long_map[kMaxChunkRows / 32];
+        zero_long_map(s_long_map);
+        __syncthreads();
+        const ChunkScratch scr{s_long_map};
+        chunk_rows<T, R, int, float>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
         return;
     }
     constexpr int VECS = kBlock / T;
