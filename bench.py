@@ -81,10 +81,12 @@ def build_local(sp, args, rank, world, dev):
     return m, cuts
 
 
-def time_steps(plan, m, x, y_local, y_full, cuts, world, steps, sp):
-    """K steps; returns (wall seconds between the two syncs, mean device ms of one execute)."""
+def time_steps(plan, m, x, y_local, y_full, cuts, use_dist, steps, sp):
+    """K steps; returns (wall seconds between the two syncs, mean device ms of one execute).
+    use_dist: a process group exists (launched by torch.distributed.run) -> every step ends
+    with the allgatherv of the y slices, and the timed region is bracketed by barriers."""
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -92,10 +94,10 @@ def time_steps(plan, m, x, y_local, y_full, cuts, world, steps, sp):
         a.record()
         plan.execute(m.Ax, x, y_local)
         b.record()
-        if world > 1:
+        if use_dist:
             sp.dist.allgatherv(y_local, y_full, cuts)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     wall = time.perf_counter() - t0
     dev_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
@@ -161,7 +163,9 @@ def main():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (RANK set): one process per GPU over RCCL, also for N = 1
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     sp = graft.load_package()
@@ -169,7 +173,7 @@ def main():
     m, cuts = build_local(sp, args, rank, world, dev)
     x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, dev)  # same seed on every rank: replicated x
     y_local = torch.empty(m.n_rows, dtype=m.Ax.dtype, device=dev)
-    y_full = torch.empty(cuts[-1], dtype=m.Ax.dtype, device=dev) if world > 1 else y_local
+    y_full = torch.empty(cuts[-1], dtype=m.Ax.dtype, device=dev) if use_dist else y_local
     flags = sp.capi.PLAN_REUSE_STRUCTURE if args.reuse_structure else 0
     plans = {k: sp.Plan(k, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype, flags)
              for k in (KINDS if args.kind == "auto" or args.all_kinds else (args.kind,))}
@@ -177,22 +181,22 @@ def main():
     # warm-up; with --kind auto the warm-up also picks the kind (outside the timed region)
     probe = {}
     for k, p in plans.items():
-        time_steps(p, m, x, y_local, y_full, cuts, world, max(args.warmup, 1), sp)   # warm-up proper
+        time_steps(p, m, x, y_local, y_full, cuts, use_dist, max(args.warmup, 1), sp)   # warm-up proper
     for k, p in plans.items():
-        _, ms = time_steps(p, m, x, y_local, y_full, cuts, world, max(args.warmup, 30), sp)
+        _, ms = time_steps(p, m, x, y_local, y_full, cuts, use_dist, max(args.warmup, 30), sp)
         probe[k] = ms
     kind = args.kind
     if kind == "auto":
         best = torch.tensor([probe[k] for k in KINDS], device=dev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(best, op=dist.ReduceOp.MAX)
         kind = KINDS[int(torch.argmin(best).item())]
     plan = plans[kind]
 
-    wall, dev_ms = time_steps(plan, m, x, y_local, y_full, cuts, world, args.steps, sp)
+    wall, dev_ms = time_steps(plan, m, x, y_local, y_full, cuts, use_dist, args.steps, sp)
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
     nnz_all = torch.tensor([m.nnz], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nnz_all, op=dist.ReduceOp.SUM)
     wall = float(tmax.item())
@@ -201,7 +205,7 @@ def main():
     others = {}
     if args.all_kinds:
         for k, p in plans.items():
-            _, ms = time_steps(p, m, x, y_local, y_full, cuts, world, args.steps, sp)
+            _, ms = time_steps(p, m, x, y_local, y_full, cuts, use_dist, args.steps, sp)
             others[k] = {"kernel_ms": ms, "gflops": 2.0 * m.nnz / ms / 1e6,
                          "gbps": m.algorithmic_bytes() / ms / 1e6}
 
@@ -236,7 +240,7 @@ def main():
         print(json.dumps(out), flush=True)
     for p in plans.values():
         p.destroy()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

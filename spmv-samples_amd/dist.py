@@ -50,9 +50,6 @@ def allgatherv(y_local, y_full, cuts, group=None):
     rank = dist.get_rank(group)
     counts = [cuts[p + 1] - cuts[p] for p in range(world)]
     assert y_local.numel() == counts[rank]
-    if world == 1:
-        y_full[cuts[0]:cuts[1]].copy_(y_local)
-        return y_full
     if len(set(counts)) == 1 and y_full.numel() == counts[0] * world:
         dist.all_gather_into_tensor(y_full, y_local, group=group)
         return y_full

@@ -1,0 +1,148 @@
+// main.cpp — the benchmark harness of peakcrosser7/spmv-samples for an MI355X box
+// (SURVEY §8(f)-2).  Same command line, same two tables, same format strings as the
+// reference's main.cu:21-124, so that the outputs of the two can be diffed:
+//
+//     ./bin/spmv <filename.mtx> <SpMV_kind_string>...
+//
+//   Dataset: <file name>                                   main.cu:38-39
+//       n_rows: R  n_cols: C  nnz: Z
+//   Compute delta:                                          main.cu:83-97
+//   [kind        ] sum: %12lf  avg: %12lf
+//   Time cost:                                              main.cu:100-113
+//   [kind        ] total: %12lf ms  kernel: %12lf ms
+//
+// x = 1 (main.cu:41), the CPU result comes from the serial host loop (main.cu:78-81),
+// every kind is called through SpMV(kind, ...) on device arrays owned by the harness
+// (main.cu:48-74), timing is the mean of TEST_TIMES = 2000 calls read from
+// Timer::total_cost / kernel_cost (main.cu:102-113).
+//
+// Differences, all behind options that come AFTER the kinds and start with "--":
+//   --iters N        TEST_TIMES (default 2000, main.cu:19)
+//   --dtype f64      value_t = double           (default float,  main.cu:17)
+//   --offset 64      offset_t = 64-bit          (default int,    main.cu:16; the reference
+//                                                harness cannot express this)
+//   --no-poison      keep y between kinds.  By default y is filled with NaN before every
+//                    kind: the reference leaves the previous kind's result in dY, so a kind
+//                    that skips rows looks correct
+//   --unit-us        label the time columns "us": the reference prints microseconds under
+//                    an "ms" label (timer.hpp:10 vs main.cu:111-112); default keeps its label
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <iostream>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "load.hpp"
+#include "spmv.h"
+#include "spmv/cpu_check.hpp"
+
+#define checkHipErr(val) CheckHipErr((val), #val, __FILE__, __LINE__)
+static void CheckHipErr(hipError_t result, const char* func, const char* file, int line) {
+    if (result != hipSuccess) {
+        std::fprintf(stderr, "HIP error at %s:%d code=%d(%s) \"%s\" \n", file, line, int(result),
+                     hipGetErrorName(result), func);
+        std::abort();   // common.cuh:13-23
+    }
+}
+
+struct Options {
+    int iters = 2000;
+    bool poison = true;
+    bool unit_us = false;
+};
+
+template <typename index_t, typename offset_t, typename value_t>
+static int run(const char* path, const std::vector<std::string>& kinds, const Options& opt) {
+    csr_t<index_t, offset_t, value_t> csr = ToCsr(LoadCoo<index_t, offset_t, value_t>(path));
+    const index_t n_rows = csr.number_of_rows, n_cols = csr.number_of_columns;
+    const offset_t nnz = csr.number_of_nonzeros;
+    std::cout << "Dataset: " << std::filesystem::path(path).filename().string() << std::endl
+              << "\tn_rows: " << n_rows << "  n_cols: " << n_cols << "  nnz: " << nnz << std::endl;
+
+    std::vector<value_t> vec_x(size_t(n_cols), value_t(1));
+    std::vector<value_t> vec_y(size_t(n_rows), value_t(0));
+
+    offset_t* dAp; index_t* dAj; value_t *dAx, *dX, *dY;
+    checkHipErr(hipSetDevice(0));   // USED_DEVICE, common.cuh:8
+    checkHipErr(hipMalloc((void**)&dAp, (size_t(n_rows) + 1) * sizeof(offset_t)));
+    checkHipErr(hipMalloc((void**)&dAj, (size_t(nnz) + 1) * sizeof(index_t)));
+    checkHipErr(hipMalloc((void**)&dAx, (size_t(nnz) + 1) * sizeof(value_t)));
+    checkHipErr(hipMalloc((void**)&dX, (size_t(n_cols) + 1) * sizeof(value_t)));
+    checkHipErr(hipMalloc((void**)&dY, (size_t(n_rows) + 1) * sizeof(value_t)));
+    checkHipErr(hipMemcpy(dAp, csr.row_offsets.data(), (size_t(n_rows) + 1) * sizeof(offset_t), hipMemcpyHostToDevice));
+    checkHipErr(hipMemcpy(dAj, csr.column_indices.data(), size_t(nnz) * sizeof(index_t), hipMemcpyHostToDevice));
+    checkHipErr(hipMemcpy(dAx, csr.nonzero_values.data(), size_t(nnz) * sizeof(value_t), hipMemcpyHostToDevice));
+    checkHipErr(hipMemcpy(dX, vec_x.data(), size_t(n_cols) * sizeof(value_t), hipMemcpyHostToDevice));
+    checkHipErr(hipMemcpy(dY, vec_y.data(), size_t(n_rows) * sizeof(value_t), hipMemcpyHostToDevice));
+
+    // CPU SpMV baseline (main.cu:76-81)
+    std::vector<value_t> correct_y(size_t(n_rows), value_t(0));
+    SpMV_cpu_navie(n_rows, n_cols, nnz, csr.row_offsets.data(), csr.column_indices.data(),
+                   csr.nonzero_values.data(), vec_x.data(), correct_y.data());
+
+    std::printf("Compute delta:\n");
+    const std::vector<value_t> poison(size_t(n_rows), std::numeric_limits<value_t>::quiet_NaN());
+    for (const auto& kind : kinds) {
+        if (opt.poison && n_rows > 0)
+            checkHipErr(hipMemcpy(dY, poison.data(), size_t(n_rows) * sizeof(value_t), hipMemcpyHostToDevice));
+        SpMV(kind, n_rows, n_cols, nnz, dAp, dAj, dAx, dX, dY);
+        checkHipErr(hipMemcpy(vec_y.data(), dY, size_t(n_rows) * sizeof(value_t), hipMemcpyDeviceToHost));
+        double delta = 0.;
+        for (index_t i = 0; i < n_rows; ++i) delta += std::abs(correct_y[i] - vec_y[i]);
+        std::printf("[%-12s] sum: %12lf  avg: %12lf\n", kind.data(), delta, delta / n_rows);
+    }
+    std::printf("\n");
+
+    std::printf("Time cost:\n");
+    for (const auto& kind : kinds) {
+        int64_t total_time = 0, kernel_time = 0;
+        for (int i = 0; i < opt.iters; ++i) {
+            SpMV(kind, n_rows, n_cols, nnz, dAp, dAj, dAx, dX, dY);
+            total_time += Timer::total_cost();
+            kernel_time += Timer::kernel_cost();
+        }
+        if (opt.unit_us)
+            std::printf("[%-12s] total: %12lf us  kernel: %12lf us\n", kind.data(), 1. * total_time / opt.iters,
+                        1. * kernel_time / opt.iters);
+        else
+            std::printf("[%-12s] total: %12lf ms  kernel: %12lf ms\n", kind.data(), 1. * total_time / opt.iters,
+                        1. * kernel_time / opt.iters);
+    }
+    checkHipErr(hipFree(dAp)); checkHipErr(hipFree(dAj)); checkHipErr(hipFree(dAx));
+    checkHipErr(hipFree(dX)); checkHipErr(hipFree(dY));
+    return EXIT_SUCCESS;
+}
+
+int main(int argc, char** argv) {
+    std::vector<std::string> kinds;
+    Options opt;
+    std::string dtype = "f32", offset = "32";
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto value = [&](const char* name) -> std::string {
+            if (i + 1 >= argc) { std::cerr << name << " needs a value" << std::endl; std::exit(1); }
+            return argv[++i];
+        };
+        if (a == "--iters") opt.iters = std::max(1, std::atoi(value("--iters").c_str()));
+        else if (a == "--dtype") dtype = value("--dtype");
+        else if (a == "--offset") offset = value("--offset");
+        else if (a == "--no-poison") opt.poison = false;
+        else if (a == "--unit-us") opt.unit_us = true;
+        else kinds.push_back(a);
+    }
+    if (argc < 3 || kinds.empty()) {
+        std::cerr << "usage: ./bin/<program-name>  <filename.mtx>  <SpMV_kind_string>..." << std::endl;
+        std::exit(1);
+    }
+    const bool f64 = dtype == "f64", o64 = offset == "64";
+    if (!f64 && !o64) return run<int, int, float>(argv[1], kinds, opt);
+    if (f64 && !o64) return run<int, int, double>(argv[1], kinds, opt);
+    if (!f64 && o64) return run<int, long long, float>(argv[1], kinds, opt);
+    return run<int, long long, double>(argv[1], kinds, opt);
+}

@@ -1,0 +1,85 @@
+"""The MI355X harness (spmv-samples_amd/host/main.cpp): argv shape, error
+behaviour of the loader it embeds (CPU), and the two tables of main.cu:83-113 (GPU)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import GOLD, ROOT
+
+EXE = os.path.join(ROOT, "spmv-samples_amd", "bin", "spmv")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "spmv-samples_amd", "csrc")], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "spmv-samples_amd", "host")], check=True)
+    return EXE
+
+
+def run(exe, *args):
+    return subprocess.run([exe, *args], capture_output=True, text=True, timeout=600)
+
+
+def test_usage_message_and_exit_code(exe):
+    """main.cu:22-25."""
+    r = run(exe)
+    assert r.returncode == 1 and "usage: ./bin/<program-name>  <filename.mtx>  <SpMV_kind_string>..." in r.stderr
+    r = run(exe, "only_a_file.mtx")
+    assert r.returncode == 1 and "usage:" in r.stderr
+
+
+@pytest.mark.parametrize("text,msg", [
+    (None, "File could not be opened"),                                                     # load.hpp:278-281
+    ("%%NotMM matrix coordinate real general\n1 1 1\n1 1 1\n", "Could not process Matrix Market banner"),
+    ("%%MatrixMarket matrix array real general\n1 1\n1\n", "File is not a sparse matrix"),    # load.hpp:289-292
+    ("%%MatrixMarket matrix coordinate real general\n% c\n", "Could not read file info (M, N, NNZ)"),
+    ("%%MatrixMarket matrix coordinate complex general\n1 1 1\n1 1 1 0\n", "Unrecognized matrix market format type"),
+])
+def test_loader_failures_exit_like_the_reference(exe, tmp_path, text, msg):
+    p = tmp_path / "m.mtx"
+    if text is not None:
+        p.write_text(text)
+    r = run(exe, str(p), "hip_vector")
+    assert r.returncode == 1
+    assert msg in r.stderr
+
+
+def test_malformed_entry_terminates_with_the_reference_message(exe, tmp_path):
+    """An uncaught exception_t, as in the reference (load.hpp:324-329): abnormal termination."""
+    p = tmp_path / "m.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n0 1 1.0\n")
+    r = run(exe, str(p), "hip_vector")
+    assert r.returncode != 0 and "Market file is zero-indexed" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--dtype", "f64"], ["--offset", "64"], ["--dtype", "f64", "--offset", "64"]])
+def test_tables_match_the_reference_format(exe, extra):
+    path = os.path.join(GOLD, "c1_1138_bus_standin.mtx")
+    kinds = ["hip_vector", "hip_merge", "hip_light"]
+    r = run(exe, path, *kinds, "--iters", "20", *extra)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert "Dataset: c1_1138_bus_standin.mtx\n\tn_rows: 1138  n_cols: 1138  nnz: 4054\n" in out   # main.cu:38-39
+    assert "Compute delta:\n" in out and "\nTime cost:\n" in out
+    for k in kinds:
+        m = re.search(r"^\[%-12s\] sum: +([0-9.eE+-]+|nan)  avg: +([0-9.eE+-]+|nan)$" % k, out, re.M)
+        assert m, out
+        # values of magnitude ~1e3 with 3-4 entries per row: fp32 sums differ from the serial
+        # order by a few ulp per row at most; NaN (a skipped row, y is poisoned) fails here
+        assert float(m.group(2)) < (1e-3 if "f64" not in extra else 1e-10)
+        t = re.search(r"^\[%-12s\] total: +([0-9.]+) ms  kernel: +([0-9.]+) ms$" % k, out, re.M)
+        assert t, out
+        assert float(t.group(2)) <= float(t.group(1))
+
+
+@pytest.mark.gpu
+def test_unknown_kind_and_unit_flag(exe):
+    path = os.path.join(GOLD, "lattice9_cub_doc.mtx")
+    r = run(exe, path, "hip_vector", "--iters", "5", "--unit-us")
+    assert r.returncode == 0 and re.search(r"total: +[0-9.]+ us  kernel: +[0-9.]+ us", r.stdout)
+    assert re.search(r"\[hip_vector  \] sum: +0\.000000  avg: +0\.000000", r.stdout)       # integer-valued: exact
+    r = run(exe, path, "cusparse")
+    assert r.returncode == 1 and 'SpMV kind "cusparse" is NOT SUPPROT' in r.stderr        # spmv.h:46-47
