@@ -167,7 +167,18 @@ def main():
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL prints a version banner on stdout when the communicator comes up; stdout is
+        # reserved for the one JSON line, so route fd 1 to stderr until the first collective is done
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     sp = graft.load_package()
 
     m, cuts = build_local(sp, args, rank, world, dev)

@@ -83,13 +83,17 @@ int probe_structure(Plan& p) {
 // rows: the full 36 KB when the sampled band plus those rows fits within 1.5x of
 // it (the kernels centre a too-small window on the span), else none.
 // MI355_SPMV_WINDOW=0|1 forces the choice (tuning / tests).
-int pick_window_elems(const Plan& p, int64_t rows_per_workgroup) {
+int pick_window_elems(Plan& p, int64_t rows_per_workgroup) {
     const int val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
     const int cap = kWindowBytes / val_bytes;
+    p.window_from_band = false;
     const char* force = getenv("MI355_SPMV_WINDOW");
     if (force) return atoi(force) ? cap : 0;
     if (!p.probe_ok) return 0;
     const int64_t span = (p.band_hi - p.band_lo + 1) + rows_per_workgroup;
+    // the band (plus the chunk's rows) all but fits: no need to sample every chunk
+    const char* band = getenv("MI355_SPMV_WINDOW_FROM_BAND");
+    p.window_from_band = band ? atoi(band) != 0 : span <= int64_t(cap) * 9 / 8;
     return span <= int64_t(cap) * 3 / 2 ? cap : 0;
 }
 

@@ -58,6 +58,7 @@ struct Plan {
     int64_t band_lo, band_hi;   // valid when probe_ok
     bool probe_ok;
     int window_elems;           // LDS window of x per workgroup, in elements; 0 = no window
+    bool window_from_band;      // place the window from band_lo/band_hi instead of sampling per chunk
     // dynamic rows
     int64_t rows_per_chunk;
     // scratch
@@ -81,7 +82,7 @@ template <typename off_t, typename val_t>
 int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s);
 
 int probe_structure(Plan& p);
-int pick_window_elems(const Plan& p, int64_t rows_per_workgroup);
+int pick_window_elems(Plan& p, int64_t rows_per_workgroup);
 void shape_vector(Plan& p);
 void shape_merge(Plan& p);
 void shape_light(Plan& p);

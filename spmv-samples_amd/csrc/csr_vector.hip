@@ -24,7 +24,7 @@ template <int T, int R, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void csr_vector_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, int32_t rows_per_chunk,
-    int32_t window_cap) {
+    int32_t window_cap, BandHint hint) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window_cap values of x
     val_t* s_x = reinterpret_cast<val_t*>(s_dyn);
     __shared__ int s_red[2 * (kBlock / kWave)];
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_window_kernel(
     const int64_t rb = int64_t(chunk) * rows_per_chunk;
     const int64_t re = min(rb + rows_per_chunk, int64_t(n_rows));
     zero_long_map(s_long_map);           // ordered before chunk_rows by stage_x_window's barriers
-    const XWindow<val_t> win = stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, s_x, window_cap, s_red);
+    const XWindow<val_t> win = stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, s_x, window_cap, s_red, hint);
     const ChunkScratch scr{s_long_map};
     chunk_rows<T, R, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
 }
@@ -77,13 +77,14 @@ template <typename off_t, typename val_t>
 static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
                                 hipStream_t s) {
     constexpr int R = rows_in_flight<val_t>();
+    const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
     const dim3 grid((unsigned)p.grid_blocks), block(kBlock);
     const off_t nnz = (off_t)p.nnz;
 #define MI355_VEC_CASE(TT)                                                                             \
     case TT:                                                                                           \
         hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, off_t, val_t>), grid, block,               \
                            size_t(p.window_elems) * sizeof(val_t), s, p.n_rows, p.n_cols, nnz, Ap,     \
-                           p.Aj, Ax, x, y, (int32_t)p.rows_per_chunk, (int32_t)p.window_elems);        \
+                           p.Aj, Ax, x, y, (int32_t)p.rows_per_chunk, (int32_t)p.window_elems, hint);  \
         break;
     switch (p.lanes_per_row) {
         MI355_VEC_CASE(2)

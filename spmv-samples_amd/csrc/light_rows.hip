@@ -48,7 +48,7 @@ template <int T, int R, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
-    unsigned long long* __restrict__ counters, int32_t rows_per_chunk, int32_t window_cap) {
+    unsigned long long* __restrict__ counters, int32_t rows_per_chunk, int32_t window_cap, BandHint hint) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window_cap values of x
     val_t* s_x = reinterpret_cast<val_t*>(s_dyn);
     __shared__ int s_red[2 * (kBlock / kWave)];
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
             const int64_t chunk_end = min(chunk_begin + rows_per_chunk, shard_end);
             // (stage_x_window's barriers also order this read of s_got before the next write)
             const XWindow<val_t> win = stage_x_window<off_t, val_t>(
-                chunk_begin, chunk_end, n_cols, Ap, Aj, x, s_x, window_cap, s_red);
+                chunk_begin, chunk_end, n_cols, Ap, Aj, x, s_x, window_cap, s_red, hint);
             chunk_rows<T, R, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
             __syncthreads();  // every wave is done with the window before it is refilled
         }
@@ -148,6 +148,7 @@ template <typename off_t, typename val_t>
 static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
                                hipStream_t s) {
     constexpr int R = light_rows_in_flight<val_t>();
+    const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
     const dim3 grid((unsigned)p.grid_blocks), block(kBlock);
     const off_t nnz = (off_t)p.nnz;
     const int32_t chunk = (int32_t)p.rows_per_chunk;
@@ -155,7 +156,7 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
     case TT:                                                                                             \
         hipLaunchKernelGGL((light_rows_window_kernel<TT, R, off_t, val_t>), grid, block,                 \
                            size_t(p.window_elems) * sizeof(val_t), s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, \
-                           Ax, x, y, p.counters, chunk, (int32_t)p.window_elems);                        \
+                           Ax, x, y, p.counters, chunk, (int32_t)p.window_elems, hint);                  \
         break;
     switch (p.lanes_per_row) {
         MI355_LIGHT_CASE(2)

@@ -129,6 +129,12 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
         }
     };
     if constexpr (VEC) issue(y0, y1);
+    // the first kBlock row ends of a tile are fetched one tile ahead as well (a tile with more
+    // rows than that — mean row length below 8 — loads the rest when it gets there)
+    auto fetch_row_end = [&](int xa, int xe) -> int64_t {
+        return (tid < xe - xa) ? int64_t(Ap[int64_t(xa) + tid + 1]) : int64_t(0);
+    };
+    int64_t re_next = fetch_row_end(x0, x1);
 
     val_t block_carry = val_t(0);   // sum so far of the row left open by the previous tile of this run
     for (int64_t t = first; t < last; ++t) {
@@ -165,9 +171,11 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
             }
         }
         // (2) row ends, relative to y0; the row still open at the tile end never ends here
-        for (int i = tid; i <= tr; i += kBlock) {
+        if (tid <= tr) s_re[tid] = (tid < tr) ? int(re_next - y0) : INT_MAX;
+        for (int i = tid + kBlock; i <= tr; i += kBlock) {
             s_re[i] = (i < tr) ? int(int64_t(Ap[int64_t(x0) + i + 1]) - y0) : INT_MAX;
         }
+        if (t + 1 < last) re_next = fetch_row_end(x1, x2);
         __syncthreads();
 
         // (3) this thread's piece of the merge path: items [d0, d1) of the tile

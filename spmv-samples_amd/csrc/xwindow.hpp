@@ -53,14 +53,36 @@ __device__ __forceinline__ int wave_max(int v) {
 // Workgroup-wide: sample the column range of rows [rb, re), copy that window of x
 // into s_x (capacity `cap` elements).  All kBlock threads must call; ends with a
 // barrier.  s_red: 2 * (kBlock / kWave) ints of LDS scratch.
+// BandHint: the band [lo, hi] of (column - row) the plan's probe saw (analyze.hip).  When the
+// whole band of a chunk fits the window (use == true) the window is placed from it and
+// the per-chunk sample — two dependent loads and a barrier — is skipped.
+struct BandHint {
+    int64_t lo, hi;
+    bool use;
+};
+
 template <typename off_t, typename val_t>
 __device__ __forceinline__ XWindow<val_t> stage_x_window(int64_t rb, int64_t re, int32_t n_cols,
                                                          const off_t* __restrict__ Ap,
                                                          const int32_t* __restrict__ Aj,
                                                          const val_t* __restrict__ x, val_t* s_x,
-                                                         int32_t cap, int* s_red) {
+                                                         int32_t cap, int* s_red,
+                                                         const BandHint hint = BandHint{0, 0, false}) {
     const int tid = threadIdx.x;
     int lo = INT32_MAX, hi = -1;
+    if (cap <= 0) {        // the plan decided against a window: no sampling
+        XWindow<val_t> none;
+        none.s_x = s_x;
+        none.lo = 0;
+        none.len = 0;
+        __syncthreads();   // callers rely on this function being a workgroup barrier
+        return none;
+    }
+    if (hint.use && re > rb) {
+        const int64_t l = rb + hint.lo, h = re - 1 + hint.hi;
+        lo = int(l < 0 ? 0 : (l >= n_cols ? n_cols - 1 : l));
+        hi = int(h < 0 ? 0 : (h >= n_cols ? n_cols - 1 : h));
+    } else {
     // kSamples rows spread evenly over the chunk, first and last row included.  NOT
     // every row: the first and last column of a 32-nonzero row sit in the two cache
     // lines that hold the whole row of Aj, so sampling every row re-reads all of Aj
@@ -85,6 +107,7 @@ __device__ __forceinline__ XWindow<val_t> stage_x_window(int64_t rb, int64_t re,
     __syncthreads();
     lo = s_red[0];
     hi = s_red[1];
+    }
     XWindow<val_t> win;
     win.s_x = s_x;
     if (hi < 0) {          // no sampled row has a nonzero: no window, every gather goes to global
@@ -103,7 +126,7 @@ __device__ __forceinline__ XWindow<val_t> stage_x_window(int64_t rb, int64_t re,
         __syncthreads();
         return win;
     }
-    int len = span + 2 * (span / 8 + 64);
+    int len = hint.use ? span : span + 2 * (span / 8 + 64);
     if (len > cap) len = cap;
     if (len > n_cols) len = n_cols;
     int64_t start = (int64_t(lo) + hi + 1 - len) / 2;
@@ -130,7 +153,8 @@ __device__ __forceinline__ val_t window_gather(const XWindow<val_t>& win, const 
                                                int32_t col, bool needed) {
     const unsigned rel = unsigned(col - win.lo);
     const bool in = rel < unsigned(win.len);
-    val_t v = win.s_x[in ? rel : 0u];
+    val_t v = val_t(0);
+    if (in) v = win.s_x[rel];          // (with no window, len == 0 and s_x may have no storage)
     if (needed && !in) v = x[col];
     return v;
 }
