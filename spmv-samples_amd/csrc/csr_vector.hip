@@ -20,22 +20,20 @@
 
 namespace mi355 {
 
-template <int T, int R, typename off_t, typename val_t>
+template <int T, int R, bool WINDOW, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void csr_vector_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, int32_t rows_per_chunk,
     int32_t window_cap, BandHint hint) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window_cap values of x
-    val_t* s_x = reinterpret_cast<val_t*>(s_dyn);
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2 * (kBlock / kWave)];
-    __shared__ unsigned s_long_map[kMaxChunkRows / 32];
+    const ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, rows_per_chunk);
     const unsigned chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int64_t rb = int64_t(chunk) * rows_per_chunk;
     const int64_t re = min(rb + rows_per_chunk, int64_t(n_rows));
-    zero_long_map(s_long_map);           // ordered before chunk_rows by stage_x_window's barriers
-    const XWindow<val_t> win = stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, s_x, window_cap, s_red, hint);
-    const ChunkScratch scr{s_long_map};
-    chunk_rows<T, R, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
+    stage_chunk_bounds<off_t, val_t>(scr, rb, re, Ap);      // ordered before chunk_rows by the barrier below
+    const XWindow<val_t> win = stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
+    chunk_rows<T, R, WINDOW, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
 }
 
 template <int T, typename off_t, typename val_t>
@@ -80,11 +78,14 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
     const dim3 grid((unsigned)p.grid_blocks), block(kBlock);
     const off_t nnz = (off_t)p.nnz;
-#define MI355_VEC_CASE(TT)                                                                             \
-    case TT:                                                                                           \
-        hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, off_t, val_t>), grid, block,               \
-                           size_t(p.window_elems) * sizeof(val_t), s, p.n_rows, p.n_cols, nnz, Ap,     \
-                           p.Aj, Ax, x, y, (int32_t)p.rows_per_chunk, (int32_t)p.window_elems, hint);  \
+    const size_t lds = chunk_lds_bytes(p.window_elems, int(p.rows_per_chunk), sizeof(off_t), sizeof(val_t));
+#define MI355_VEC_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, (int32_t)p.rows_per_chunk, (int32_t)p.window_elems, hint
+#define MI355_VEC_CASE(TT)                                                                                   \
+    case TT:                                                                                                 \
+        if (p.window_elems > 0)                                                                              \
+            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
+        else                                                                                                 \
+            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS); \
         break;
     switch (p.lanes_per_row) {
         MI355_VEC_CASE(2)
@@ -98,6 +99,7 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
             return MI355_SPMV_EINVAL;
     }
 #undef MI355_VEC_CASE
+#undef MI355_VEC_ARGS
     MI355_HIP_TRY(hipGetLastError());
     return MI355_SPMV_OK;
 }
@@ -136,7 +138,7 @@ int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* 
     // that passes an offset view gets the 4-byte-per-lane form instead.
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
-    if (aligned) return launch_vector_window<off_t, val_t>(p, Ap, Ax, x, y, s);
+    if (aligned && p.nnz >= 4) return launch_vector_window<off_t, val_t>(p, Ap, Ax, x, y, s);
     return launch_vector_plain<off_t, val_t>(p, Ap, Ax, x, y, s);
 }
 

@@ -30,6 +30,8 @@
 // the first dequeue at or past the shard's end, which every workgroup reaches
 // whatever the interleaving, so the grid always drains.
 
+#include <cstdlib>
+
 #include "common.hpp"
 #include "row_dot.hpp"
 #include "xwindow.hpp"
@@ -44,17 +46,15 @@ __device__ __forceinline__ unsigned long long wave_broadcast_u64(unsigned long l
     return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
-template <int T, int R, typename off_t, typename val_t>
+template <int T, int R, bool WINDOW, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
     unsigned long long* __restrict__ counters, int32_t rows_per_chunk, int32_t window_cap, BandHint hint) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window_cap values of x
-    val_t* s_x = reinterpret_cast<val_t*>(s_dyn);
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2 * (kBlock / kWave)];
-    __shared__ unsigned s_long_map[kMaxChunkRows / 32];
     __shared__ unsigned long long s_got;
-    const ChunkScratch scr{s_long_map};
+    const ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, rows_per_chunk);
     const int home = blockIdx.x % kXcds;
     for (int visit = 0; visit < kXcds; ++visit) {
         const int shard = (home + visit) % kXcds;
@@ -64,15 +64,15 @@ __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
             if (threadIdx.x == 0) {
                 s_got = atomicAdd(&counters[shard * kCounterStride], (unsigned long long)rows_per_chunk);
             }
-            zero_long_map(s_long_map);
             __syncthreads();
             const int64_t chunk_begin = shard_begin + int64_t(wave_broadcast_u64(s_got));
             if (chunk_begin >= shard_end) break;  // uniform over the workgroup
             const int64_t chunk_end = min(chunk_begin + rows_per_chunk, shard_end);
             // (stage_x_window's barriers also order this read of s_got before the next write)
+            stage_chunk_bounds<off_t, val_t>(scr, chunk_begin, chunk_end, Ap);   // before the barrier below
             const XWindow<val_t> win = stage_x_window<off_t, val_t>(
-                chunk_begin, chunk_end, n_cols, Ap, Aj, x, s_x, window_cap, s_red, hint);
-            chunk_rows<T, R, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+                chunk_begin, chunk_end, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
+            chunk_rows<T, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
             __syncthreads();  // every wave is done with the window before it is refilled
         }
         __syncthreads();      // s_got read by all before the next shard's dequeue overwrites it
@@ -125,9 +125,11 @@ void shape_light(Plan& p) {
     p.lanes_per_row = pick_lanes_per_row(p.nnz, p.n_rows, p.elems_per_lane);
     const int R = p.val_type == MI355_VAL_F64 ? light_rows_in_flight<double>() : light_rows_in_flight<float>();
     const int64_t pass = int64_t(kBlock / p.lanes_per_row) * R;
-    // chunks: half the size of the static kind's, so that there are >= ~8 per resident
-    // workgroup to balance with, but never below one pass of the workgroup
-    int64_t chunk = pick_rows_per_chunk(p.nnz, p.n_rows, p.lanes_per_row, R) / 2;
+    const char* ev = getenv("MI355_LIGHT_CHUNK_DIV");
+    const int64_t env_div = ev && atoi(ev) > 0 ? atoi(ev) : 1;
+    // chunks: the static kind's size (halving them cost 6 % on the S32-band target: the
+    // window of x is staged per chunk), never below one pass of the workgroup
+    int64_t chunk = pick_rows_per_chunk(p.nnz, p.n_rows, p.lanes_per_row, R) / env_div;
     chunk = (chunk + pass - 1) / pass * pass;
     if (chunk < pass) chunk = pass;
     p.rows_per_chunk = chunk;
@@ -136,7 +138,8 @@ void shape_light(Plan& p) {
     // persistent grid: 4 workgroups per CU with the 36 KB window, 5 without (VGPR-bound),
     // fewer for small inputs
     int64_t blocks = p.n_tiles;
-    const int64_t resident = int64_t(kCus) * (p.window_elems ? 4 : 5);
+    const char* er = getenv("MI355_LIGHT_BLOCKS_PER_CU");
+    const int64_t resident = int64_t(kCus) * (er && atoi(er) > 0 ? atoi(er) : (p.window_elems ? 4 : 5));
     if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
     p.grid_blocks = blocks;
@@ -152,11 +155,14 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
     const dim3 grid((unsigned)p.grid_blocks), block(kBlock);
     const off_t nnz = (off_t)p.nnz;
     const int32_t chunk = (int32_t)p.rows_per_chunk;
-#define MI355_LIGHT_CASE(TT)                                                                             \
-    case TT:                                                                                             \
-        hipLaunchKernelGGL((light_rows_window_kernel<TT, R, off_t, val_t>), grid, block,                 \
-                           size_t(p.window_elems) * sizeof(val_t), s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, \
-                           Ax, x, y, p.counters, chunk, (int32_t)p.window_elems, hint);                  \
+    const size_t lds = chunk_lds_bytes(p.window_elems, chunk, sizeof(off_t), sizeof(val_t));
+#define MI355_LIGHT_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, p.counters, chunk, (int32_t)p.window_elems, hint
+#define MI355_LIGHT_CASE(TT)                                                                                   \
+    case TT:                                                                                                   \
+        if (p.window_elems > 0)                                                                                \
+            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
+        else                                                                                                   \
+            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS); \
         break;
     switch (p.lanes_per_row) {
         MI355_LIGHT_CASE(2)
@@ -207,7 +213,7 @@ int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x
     MI355_HIP_TRY(hipMemsetAsync(p.counters, 0, sizeof(unsigned long long) * kCounterStride * kXcds, s));
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
-    if (aligned) return launch_light_window<off_t, val_t>(p, Ap, Ax, x, y, s);
+    if (aligned && p.nnz >= 4) return launch_light_window<off_t, val_t>(p, Ap, Ax, x, y, s);
     return launch_light_plain<off_t, val_t>(p, Ap, Ax, x, y, s);
 }
 

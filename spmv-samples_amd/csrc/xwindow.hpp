@@ -159,16 +159,42 @@ __device__ __forceinline__ val_t window_gather(const XWindow<val_t>& win, const 
     return v;
 }
 
-// LDS scratch of one workgroup for chunk_rows.
-constexpr int kMaxChunkRows = 8192;   // upper bound of rows per chunk (pick_rows_per_chunk)
+// LDS scratch of one workgroup for chunk_rows, carved from dynamic LDS behind the window:
+//   [ window_elems values of x ][ rows+1 row bounds (off_t) ][ rows results (val_t) ][ rows/32 flag words ]
+constexpr int kMaxChunkRows = 2048;   // upper bound of rows per chunk (pick_rows_per_chunk)
 constexpr int kLongSteps = 16;        // a row is "long" beyond this many steps of its T-lane vector
+
+__host__ __device__ inline size_t lds_align16(size_t v) { return (v + 15) & ~size_t(15); }
+__host__ __device__ inline size_t chunk_lds_bytes(int window_elems, int rows, size_t off_bytes, size_t val_bytes) {
+    return lds_align16(size_t(window_elems) * val_bytes) + lds_align16(size_t(rows + 1) * off_bytes) +
+           lds_align16(size_t(rows) * val_bytes) + lds_align16(size_t(rows / 32 + 1) * 4);
+}
+
+template <typename off_t, typename val_t>
 struct ChunkScratch {
-    // one bit per row of the chunk: set = long row, summed in the second pass.
-    // Zeroed by the caller (zero_long_map) before the barrier that precedes chunk_rows.
-    unsigned* long_map;   // [kMaxChunkRows / 32]
+    val_t* s_x;           // window_elems
+    off_t* s_b;           // rows + 1 : Ap[chunk_begin .. chunk_end]
+    val_t* s_y;           // rows     : results of the chunk, stored to y in one coalesced sweep
+    unsigned* long_map;   // rows / 32 + 1 : one bit per row, set = long row, summed in the second pass
+    __device__ ChunkScratch(unsigned char* base, int window_elems, int rows) {
+        s_x = reinterpret_cast<val_t*>(base);
+        base += lds_align16(size_t(window_elems) * sizeof(val_t));
+        s_b = reinterpret_cast<off_t*>(base);
+        base += lds_align16(size_t(rows + 1) * sizeof(off_t));
+        s_y = reinterpret_cast<val_t*>(base);
+        base += lds_align16(size_t(rows) * sizeof(val_t));
+        long_map = reinterpret_cast<unsigned*>(base);
+    }
 };
-__device__ __forceinline__ void zero_long_map(unsigned* long_map) {
-    for (int i = threadIdx.x; i < kMaxChunkRows / 32; i += kBlock) long_map[i] = 0u;
+
+// Before the barrier that precedes chunk_rows (stage_x_window's): copy the chunk's row
+// bounds into LDS and clear the long-row flags.
+template <typename off_t, typename val_t>
+__device__ __forceinline__ void stage_chunk_bounds(const ChunkScratch<off_t, val_t>& scr, int64_t chunk_begin,
+                                                   int64_t chunk_end, const off_t* __restrict__ Ap) {
+    const int rows = int(chunk_end - chunk_begin);
+    for (int i = threadIdx.x; i <= rows; i += kBlock) scr.s_b[i] = Ap[chunk_begin + i];
+    for (int i = threadIdx.x; i < rows / 32 + 1; i += kBlock) scr.long_map[i] = 0u;
 }
 
 // One step of 4 nonzeros of one lane: Aj/Ax group at j (16-byte aligned element index).
@@ -190,73 +216,133 @@ __device__ __forceinline__ void load_group(off_t j, off_t nnz, const int32_t* __
     }
 }
 
-// Rows [chunk_begin, chunk_end) by this workgroup: T lanes per row, R rows per
-// vector in flight (R x the bytes in flight of one row: the loads of the R rows are
-// issued back to back before any is consumed), 4 nonzeros per lane per step.
-// A row longer than kLongSteps steps is not walked by its T lanes (a power-law hub
-// row would serialise the whole chunk behind one vector — the weakness of the
-// reference's CSR-vector and LightSpMV kernels on such inputs): its bit is set in an
-// LDS bitmap and a second pass sums every marked row with a whole 64-lane wave,
-// 512 nonzeros per step, the four waves taking marked rows in turn.
-// All kBlock threads must call (wave-wide shuffles and one barrier inside).
-template <int T, int R, typename off_t, typename val_t>
+// Rows [chunk_begin, chunk_end) by this workgroup: T lanes per row, R rows per vector per
+// group, 4 nonzeros per lane per step.  Structure (each point is a measured win on the
+// S32-band target, tools/exp_pipe.hip):
+//  * row bounds come from LDS (stage_chunk_bounds), so the only vector-memory traffic in
+//    the loop is the Aj/Ax stream itself;
+//  * the loop is software-pipelined by hand: the stream loads of group g+1 are issued
+//    BEFORE group g is consumed, into a second register set (2x unrolled ping-pong: a
+//    register copy of a pending load would force a wait), with branch-free clamped
+//    addresses (hipcc puts s_waitcnt vmcnt(0) after conditional loads), so ~8 KB per wave
+//    stay in flight while the wave computes;
+//  * a column outside the window is fetched AND consumed inside its own branch, so the
+//    common path never waits for it;
+//  * results go to LDS and leave in one coalesced nontemporal sweep per chunk: one 4-byte
+//    store per row straight from the loop cost 13 % of the kernel, although y is 1.5 % of
+//    the bytes;
+//  * a row longer than kLongSteps steps is not walked by its T lanes (a power-law hub row
+//    would serialise the chunk behind one vector — the weakness of the reference's
+//    CSR-vector and LightSpMV kernels): its bit is set in an LDS bitmap and a second pass
+//    sums every marked row with a whole 64-lane wave, the four waves taking rows in turn.
+// All kBlock threads must call (wave-wide shuffles and barriers inside); the caller has
+// run stage_chunk_bounds + a barrier.
+template <int T, int R, bool WINDOW, typename off_t, typename val_t>
 __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_end, off_t nnz,
                                            const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
                                            const val_t* __restrict__ Ax, const val_t* __restrict__ x,
                                            val_t* __restrict__ y, const XWindow<val_t>& win,
-                                           const ChunkScratch& scr) {
+                                           const ChunkScratch<off_t, val_t>& scr) {
     using v4 = typename Vec4<val_t>::type;
     constexpr int VECS = kBlock / T;
+    constexpr int STRIDE = VECS * R;                       // rows per group
     constexpr off_t LONG = off_t(T) * 4 * kLongSteps;
     const int lane = threadIdx.x & (T - 1);
     const int vec = threadIdx.x / T;
-    for (int64_t base = chunk_begin; base < chunk_end; base += VECS * R) {
-        const int64_t row0 = base + int64_t(vec) * R;
-        off_t bound[R + 1];
+    const int rows = int(chunk_end - chunk_begin);
+    const int n_groups = (rows + STRIDE - 1) / STRIDE;
+    const off_t nnz_vec = nnz & ~off_t(3);                 // 16-byte loads stay below this element
+    const off_t j_max = nnz_vec - 4;                       // callers guarantee nnz >= 4 (launch_*: plain kernel otherwise)
+
+    struct Group {
+        off_t b[R + 1];   // bounds of the vector's R rows
+        off_t j[R];       // first element of this lane's step-0 group
+        int4v c[R];
+        v4 a[R];
+    };
+    // issue the step-0 loads of group g (g may be past the end: rows clamp to empty)
+    auto issue = [&](int g, Group& G) {
 #pragma unroll
-        for (int r = 0; r <= R; ++r) {
-            const int64_t row = row0 + r;
-            bound[r] = Ap[row < chunk_end ? row : chunk_end];   // rows past the chunk become empty
+        for (int r = 0; r <= R; ++r) G.b[r] = scr.s_b[min(g * STRIDE + vec * R + r, rows)];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            G.j[r] = (G.b[r] & ~off_t(3)) + off_t(lane) * 4;
+            off_t jl = G.j[r] < G.b[r + 1] ? G.j[r] : (G.b[r] & ~off_t(3));
+            jl = jl < j_max ? jl : j_max;
+            // straight-line, branch-free: hipcc serialises (vmcnt(0)) around loads in branches
+            G.c[r] = stream_load(reinterpret_cast<const int4v*>(Aj + jl));
+            G.a[r] = stream_load(reinterpret_cast<const v4*>(Ax + jl));
         }
-        off_t j[R];
+    };
+    // sum += a[e] * x[c[e]] for the elements k = j+e inside [lo, hi).  WINDOW: x comes from the
+    // LDS window (unconditional ds_read at a clamped address + select); the rare column
+    // outside it is fetched and consumed under ONE branch per 4 elements, so the common path
+    // never waits on vector memory.  !WINDOW: plain gathers (masked elements hold a legal
+    // column of a neighbouring row, or 0, so the address is always in range).
+    auto accumulate = [&](val_t& sum, const int4v& c, const v4& a, off_t j, off_t lo, off_t hi) {
+        if constexpr (WINDOW) {
+            bool need[4];
+            bool any_need = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const off_t k = j + e;
+                const bool valid = (k >= lo) && (k < hi);
+                const unsigned rel = unsigned(c[e] - win.lo);
+                const bool in = rel < unsigned(win.len);
+                const val_t xv = win.s_x[in ? rel : 0u];
+                sum = (valid && in) ? (sum + a[e] * xv) : sum;
+                need[e] = valid && !in;
+                any_need |= need[e];
+            }
+            if (any_need) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (need[e]) sum += a[e] * x[c[e]];
+                }
+            }
+        } else {
+            val_t xv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = x[c[e]];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const off_t k = j + e;
+                sum = ((k >= lo) && (k < hi)) ? (sum + a[e] * xv[e]) : sum;
+            }
+        }
+    };
+    auto consume = [&](int g, const Group& G) {
+        const int local0 = g * STRIDE + vec * R;
         val_t sum[R];
+        off_t jn[R], hi[R];
         bool deferred[R];
         bool more = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            deferred[r] = (bound[r + 1] - bound[r]) > LONG;     // uniform over the T lanes of the vector
-            if (deferred[r] && lane == 0) {
-                const unsigned rel = unsigned(row0 + r - chunk_begin);
-                atomicOr(&scr.long_map[rel >> 5], 1u << (rel & 31));
-            }
-            j[r] = deferred[r] ? bound[r + 1] : (bound[r] & ~off_t(3)) + off_t(lane) * 4;
+            deferred[r] = (G.b[r + 1] - G.b[r]) > LONG;    // uniform over the T lanes of the vector
+            // the 16-byte path covers elements below nnz_vec; a long row is left to pass 2
+            hi[r] = deferred[r] ? G.b[r] : (G.b[r + 1] < nnz_vec ? G.b[r + 1] : nnz_vec);
             sum[r] = val_t(0);
-            more |= j[r] < bound[r + 1];
+            accumulate(sum[r], G.c[r], G.a[r], G.j[r], G.b[r], hi[r]);
+            jn[r] = G.j[r] + off_t(T) * 4;
+            more |= jn[r] < hi[r];
         }
-        while (more) {
-            int4v c[R];
-            v4 a[R];
+        while (more) {                                     // rows longer than one step (4T nonzeros)
+            int4v c2[R];
+            v4 a2[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (j[r] < bound[r + 1]) {
-                    load_group<off_t, val_t>(j[r], nnz, Aj, Ax, c[r], a[r]);
-                } else {
-                    c[r] = int4v{0, 0, 0, 0};
-                    a[r] = v4{0, 0, 0, 0};
-                }
+                off_t jl = jn[r] < hi[r] ? jn[r] : (G.b[r] & ~off_t(3));
+                jl = jl < j_max ? jl : j_max;
+                c2[r] = stream_load(reinterpret_cast<const int4v*>(Aj + jl));
+                a2[r] = stream_load(reinterpret_cast<const v4*>(Ax + jl));
             }
             more = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const off_t k = j[r] + e;
-                    const bool valid = (k >= bound[r]) && (k < bound[r + 1]);
-                    const val_t xv = window_gather<val_t>(win, x, c[r][e], valid);
-                    sum[r] = valid ? (sum[r] + a[r][e] * xv) : sum[r];
-                }
-                j[r] += off_t(T) * 4;
-                more |= j[r] < bound[r + 1];
+                accumulate(sum[r], c2[r], a2[r], jn[r], G.b[r], hi[r]);   // (clamped loads are masked by hi)
+                jn[r] += off_t(T) * 4;
+                more |= jn[r] < hi[r];
             }
         }
 #pragma unroll
@@ -264,8 +350,29 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
         if (lane == 0) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (row0 + r < chunk_end && !deferred[r]) y[row0 + r] = sum[r];
+                if (local0 + r >= rows) continue;
+                if (deferred[r]) {
+                    const unsigned rel = unsigned(local0 + r);
+                    atomicOr(&scr.long_map[rel >> 5], 1u << (rel & 31));
+                    continue;
+                }
+                if (G.b[r + 1] > nnz_vec) {                // the last (partial) group of the arrays
+                    for (off_t k = (G.b[r] > nnz_vec ? G.b[r] : nnz_vec); k < G.b[r + 1]; ++k)
+                        sum[r] += Ax[k] * x[Aj[k]];
+                }
+                scr.s_y[local0 + r] = sum[r];
             }
+        }
+    };
+
+    {
+        Group G0, G1;
+        issue(0, G0);
+        for (int g = 0; g < n_groups; g += 2) {
+            issue(g + 1, G1);
+            consume(g, G0);
+            issue(g + 2, G0);
+            consume(g + 1, G1);
         }
     }
 
@@ -273,16 +380,16 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     __syncthreads();
     const int lane64 = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    const int words = int((chunk_end - chunk_begin + 31) >> 5);
+    const int words = (rows + 31) >> 5;
     int turn = 0;                                   // marked rows are dealt to the waves in turn
     for (int w = 0; w < words; ++w) {
         unsigned bits = scr.long_map[w];            // same value in every lane
         while (bits) {
-            const int b = __ffs(bits) - 1;
+            const int bpos = __ffs(bits) - 1;
             bits &= bits - 1;
             if ((turn++ & (kBlock / kWave - 1)) != wave) continue;   // wave-uniform
-            const int64_t row = chunk_begin + (int64_t(w) << 5) + b;
-            const off_t start = Ap[row], end = Ap[row + 1];
+            const int local = (w << 5) + bpos;
+            const off_t start = scr.s_b[local], end = scr.s_b[local + 1];
             val_t sum = val_t(0);
             for (off_t j = (start & ~off_t(3)) + off_t(lane64) * 4; j < end; j += off_t(kWave) * 8) {
                 int4v c0, c1;
@@ -291,22 +398,27 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
                 load_group<off_t, val_t>(j, nnz, Aj, Ax, c0, a0);
                 if (j1 < end) load_group<off_t, val_t>(j1, nnz, Aj, Ax, c1, a1);
                 else { c1 = int4v{0, 0, 0, 0}; a1 = v4{0, 0, 0, 0}; }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool valid = (j + e >= start) && (j + e < end);
-                    const val_t xv = window_gather<val_t>(win, x, c0[e], valid);
-                    sum = valid ? (sum + a0[e] * xv) : sum;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool valid = (j1 + e < end);
-                    const val_t xv = window_gather<val_t>(win, x, c1[e], valid);
-                    sum = valid ? (sum + a1[e] * xv) : sum;
-                }
+                accumulate(sum, c0, a0, j, start, end);
+                accumulate(sum, c1, a1, j1, start, end);
             }
             sum = vector_reduce<kWave, val_t>(sum);
-            if (lane64 == 0) y[row] = sum;
+            if (lane64 == 0) scr.s_y[local] = sum;
         }
+    }
+
+    // the chunk's results: one coalesced sweep (16-byte nontemporal stores when y is aligned)
+    __syncthreads();
+    val_t* const yc = y + chunk_begin;
+    constexpr int PER16 = 16 / int(sizeof(val_t));
+    if ((reinterpret_cast<uintptr_t>(yc) & 15u) == 0) {
+        using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
+        const int full = rows / PER16;
+        for (int g = threadIdx.x; g < full; g += kBlock)
+            __builtin_nontemporal_store(*reinterpret_cast<const v16*>(scr.s_y + g * PER16),
+                                        reinterpret_cast<v16*>(yc + g * PER16));
+        for (int i = full * PER16 + threadIdx.x; i < rows; i += kBlock) yc[i] = scr.s_y[i];
+    } else {
+        for (int i = threadIdx.x; i < rows; i += kBlock) yc[i] = scr.s_y[i];
     }
 }
 
