@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void merge_search_kernel(
 }
 
 // ---- K7: one run of consecutive tiles per workgroup ---------------------------------
-template <int IPT, bool VEC, typename off_t, typename val_t>
+template <int IPT, bool VEC, bool WINDOW, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     int32_t n_rows, int32_t n_cols, int64_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
@@ -115,20 +115,21 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     // registers holding the Aj/Ax groups of the tile about to be processed
     int4v c[G];
     v4 a[G];
-    auto issue = [&](int64_t ya, int64_t ye) {
+    // branch-free: addresses are clamped below the last whole 16-byte group of the arrays (hipcc
+    // serialises loads it finds in branches); the few nonzeros at or past nnz_vec are redone below
+    const int64_t nnz_vec = nnz & ~int64_t(3);
+    const int64_t j_max = nnz_vec - 4;                 // VEC launches guarantee nnz >= 4
+    auto issue = [&](int64_t ya) {
         const int64_t base = ya & ~int64_t(3);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const int64_t j = base + 4 * int64_t(tid + g * kBlock);
-            if (j < ye) {
-                load_group<int64_t, val_t>(j, nnz, Aj, Ax, c[g], a[g]);
-            } else {
-                c[g] = int4v{0, 0, 0, 0};
-                a[g] = v4{0, 0, 0, 0};
-            }
+            int64_t j = base + 4 * int64_t(tid + g * kBlock);
+            j = j < j_max ? j : j_max;
+            c[g] = stream_load(reinterpret_cast<const int4v*>(Aj + j));
+            a[g] = stream_load(reinterpret_cast<const v4*>(Ax + j));
         }
     };
-    if constexpr (VEC) issue(y0, y1);
+    if constexpr (VEC) issue(y0);
     // the first kBlock row ends of a tile are fetched one tile ahead as well (a tile with more
     // rows than that — mean row length below 8 — loads the rest when it gets there)
     auto fetch_row_end = [&](int xa, int xe) -> int64_t {
@@ -150,19 +151,49 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
 
         // (1) products a*x for the tile's nonzeros
         if constexpr (VEC) {
+            if constexpr (WINDOW) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int rel = 4 * (tid + g * kBlock) - shift;   // tile-relative index of element 0
-                v4 p;
+                for (int g = 0; g < G; ++g) {
+                    const int rel0 = 4 * (tid + g * kBlock) - shift;   // tile-relative index of element 0
+                    v4 p;
+                    bool need[4];
+                    bool any_need = false;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool needed = (rel + e >= 0) && (rel + e < tn);
-                    p[e] = a[g][e] * window_gather<val_t>(win, x, c[g][e], needed);
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned rel = unsigned(c[g][e] - win.lo);
+                        const bool in = rel < unsigned(win.len);
+                        p[e] = a[g][e] * win.s_x[in ? rel : 0u];
+                        need[e] = !in && (rel0 + e >= 0) && (rel0 + e < tn);
+                        any_need |= need[e];
+                    }
+                    if (any_need) {                      // rare: loaded and consumed inside the branch
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (need[e]) p[e] = a[g][e] * x[c[g][e]];
+                        }
+                    }
+                    *reinterpret_cast<v4*>(&s_nz[4 * (tid + g * kBlock)]) = p;
                 }
-                *reinterpret_cast<v4*>(&s_nz[4 * (tid + g * kBlock)]) = p;
+            } else {
+                val_t xv[G][4];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[g][e] = x[c[g][e]];   // every column is a loaded Aj entry: in range
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    v4 p;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p[e] = a[g][e] * xv[g][e];
+                    *reinterpret_cast<v4*>(&s_nz[4 * (tid + g * kBlock)]) = p;
+                }
+            }
+            if (y1 > nnz_vec) {   // uniform, at most one tile: the nonzeros past the last whole group
+                const int64_t k = (y0 > nnz_vec ? y0 : nnz_vec) + tid;
+                if (k < y1) s_nz[int(k - y0) + shift] = Ax[k] * x[Aj[k]];
             }
             // the next tile's stream goes in flight now and lands while this tile is walked
-            if (t + 1 < last) issue(y1, y2);
+            if (t + 1 < last) issue(y1);
         } else {
             // Aj / Ax not 16-byte aligned (an offset view): 4-byte-per-lane form
             for (int i = tid; i < tn; i += kBlock) {
@@ -317,17 +348,22 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
         MI355_HIP_TRY(hipGetLastError());
         p.coords_valid = true;
     }
-    const int32_t cap = aligned ? (int32_t)p.window_elems : 0;
+    const int32_t cap = (aligned && p.nnz >= 4) ? (int32_t)p.window_elems : 0;
     const size_t dyn = size_t(cap) * sizeof(val_t);
     const dim3 grid((unsigned)p.n_super), block(kBlock);
-#define MI355_MERGE_LAUNCH(IPT_, VEC_)                                                                         \
-    hipLaunchKernelGGL((merge_tile_kernel<IPT_, VEC_, off_t, val_t>), grid, block, dyn, s, p.n_rows, p.n_cols,  \
-                       p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz, p.carry_row,                        \
+#define MI355_MERGE_LAUNCH(IPT_, VEC_, WIN_)                                                                  \
+    hipLaunchKernelGGL((merge_tile_kernel<IPT_, VEC_, WIN_, off_t, val_t>), grid, block, dyn, s, p.n_rows,     \
+                       p.n_cols, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz, p.carry_row,              \
                        static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super, cap)
+    const bool vec = aligned && p.nnz >= 4;
     if (p.elems_per_lane == 16) {
-        if (aligned) MI355_MERGE_LAUNCH(16, true); else MI355_MERGE_LAUNCH(16, false);
+        if (!vec) MI355_MERGE_LAUNCH(16, false, false);
+        else if (cap > 0) MI355_MERGE_LAUNCH(16, true, true);
+        else MI355_MERGE_LAUNCH(16, true, false);
     } else {
-        if (aligned) MI355_MERGE_LAUNCH(8, true); else MI355_MERGE_LAUNCH(8, false);
+        if (!vec) MI355_MERGE_LAUNCH(8, false, false);
+        else if (cap > 0) MI355_MERGE_LAUNCH(8, true, true);
+        else MI355_MERGE_LAUNCH(8, true, false);
     }
 #undef MI355_MERGE_LAUNCH
     MI355_HIP_TRY(hipGetLastError());
