@@ -84,18 +84,28 @@ def build_local(sp, args, rank, world, dev):
 def time_steps(plan, m, x, y_local, y_full, cuts, use_dist, steps, sp):
     """K steps; returns (wall seconds between the two syncs, mean device ms of one execute).
     use_dist: a process group exists (launched by torch.distributed.run) -> every step ends
-    with the allgatherv of the y slices, and the timed region is bracketed by barriers."""
+    with the allgatherv of the y slices, and the timed region is bracketed by barriers.
+    The exchange of step k runs beside the SpMV of step k+1 (y_local / y_full are pairs of
+    buffers; a buffer is reused only after the exchange that read it has finished); every
+    exchange completes inside the timed region."""
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    pending = [None, None]
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for a, b in evs:
+    for i, (a, b) in enumerate(evs):
+        k = i & 1
+        if pending[k] is not None:
+            pending[k].wait()
         a.record()
-        plan.execute(m.Ax, x, y_local)
+        plan.execute(m.Ax, x, y_local[k])
         b.record()
         if use_dist:
-            sp.dist.allgatherv(y_local, y_full, cuts)
+            pending[k] = sp.dist.allgatherv(y_local[k], y_full[k], cuts, async_op=True)
+    for w in pending:
+        if w is not None:
+            w.wait()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -183,8 +193,8 @@ def main():
 
     m, cuts = build_local(sp, args, rank, world, dev)
     x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, dev)  # same seed on every rank: replicated x
-    y_local = torch.empty(m.n_rows, dtype=m.Ax.dtype, device=dev)
-    y_full = torch.empty(cuts[-1], dtype=m.Ax.dtype, device=dev) if use_dist else y_local
+    y_local = [torch.empty(m.n_rows, dtype=m.Ax.dtype, device=dev) for _ in range(2)]
+    y_full = [torch.empty(cuts[-1], dtype=m.Ax.dtype, device=dev) for _ in range(2)] if use_dist else y_local
     flags = sp.capi.PLAN_REUSE_STRUCTURE if args.reuse_structure else 0
     plans = {k: sp.Plan(k, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype, flags)
              for k in (KINDS if args.kind == "auto" or args.all_kinds else (args.kind,))}
@@ -237,8 +247,12 @@ def main():
                                    % (m.name, m.n_rows, world, m.nnz, "i32" if m.Ap.dtype == torch.int32 else "i64"),
                        "kind": kind, "lanes_per_row": info["lanes_per_row"], "grid_blocks": info["grid_blocks"],
                        "kernels_per_step": info["n_kernels"], "x_window_elems": info["window_elems"], "reuse_structure": bool(args.reuse_structure),
-                       "parallelism": "row-block x%d, x replicated, allgatherv(y)" % world if world > 1 else "single GPU"},
+                       "parallelism": ("row-block x%d, x replicated, allgatherv(y) over RCCL overlapped with the next "
+                                       "step's SpMV" % world) if use_dist else "single GPU"},
             "achieved_hbm_gbps": achieved,
+            # per-GPU SpMV alone (device time of the execute) vs the whole step incl. the exchange
+            "compute_only": {"ms": dev_ms, "gflops_per_gpu": 2.0 * m.nnz / dev_ms / 1e6,
+                             "step_ms_incl_exchange": wall / args.steps * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": read_traffic(info["main_kernel"]),
                          "kernel": info["main_kernel"], "kernel_ms": dev_ms, "algorithmic_bytes": bytes_alg},

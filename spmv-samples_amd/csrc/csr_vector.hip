@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
         start = Ap[row];
         end = Ap[row + 1];
     }
-    val_t sum = row_partial<T, 1, off_t, val_t>(start, end, nnz, lane, Aj, Ax, x);
+    val_t sum = row_partial<T, off_t, val_t>(start, end, lane, Aj, Ax, x);
     sum = vector_reduce<T, val_t>(sum);
     if (live && lane == 0) y[row] = sum;
 }

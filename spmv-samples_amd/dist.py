@@ -44,14 +44,31 @@ def shard_csr(Ap, Aj, Ax, r0, r1):
     return Ap_l, Aj[lo:hi].clone(), Ax[lo:hi].clone()
 
 
-def allgatherv(y_local, y_full, cuts, group=None):
-    """y_full[cuts[p]:cuts[p+1]] <- rank p's y_local, on every rank."""
+class _Works:
+    """Handle for an in-flight allgatherv: wait() blocks the current stream until it is done."""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
+def allgatherv(y_local, y_full, cuts, group=None, async_op=False):
+    """y_full[cuts[p]:cuts[p+1]] <- rank p's y_local, on every rank.
+    async_op=True returns a handle (wait() before y_local is overwritten or y_full is read):
+    the exchange then runs beside whatever the caller launches next (bench.py overlaps it
+    with the following SpMV, double-buffering y)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     counts = [cuts[p + 1] - cuts[p] for p in range(world)]
     assert y_local.numel() == counts[rank]
     if len(set(counts)) == 1 and y_full.numel() == counts[0] * world:
-        dist.all_gather_into_tensor(y_full, y_local, group=group)
+        w = dist.all_gather_into_tensor(y_full, y_local, group=group, async_op=True)
+        if async_op:
+            return _Works([w])
+        w.wait()
         return y_full
     y_full[cuts[rank]:cuts[rank + 1]].copy_(y_local)
     works = []
@@ -60,6 +77,8 @@ def allgatherv(y_local, y_full, cuts, group=None):
             continue
         src = dist.get_global_rank(group, p) if group is not None else p
         works.append(dist.broadcast(y_full[cuts[p]:cuts[p + 1]], src=src, group=group, async_op=True))
+    if async_op:
+        return _Works(works)
     for w in works:
         w.wait()
     return y_full

@@ -291,3 +291,31 @@ def test_full_size_fp64_i64_linearity_and_rowsums(sp, oracle, kind):
     Ap = m.Ap[:rows + 1].cpu().numpy(); Aj = m.Aj[:hi].cpu().numpy(); Ax = m.Ax[:hi].cpu().numpy()
     y64, bound = parity_bound(oracle, Ap, Aj, Ax, xa.cpu().numpy())
     assert np.all(np.abs(ya[:rows].cpu().numpy() - y64) <= bound)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_more_than_2_to_31_nonzeros_with_64bit_offsets(sp, kind):
+    """nnz = 2^31 + 2^21 > INT32_MAX: only expressible with offset_t = int64 (the reference's
+    harness cannot; its loader overflows there, quirk 2).  Values are 1.0 and
+    x = 1, so y must equal the row lengths exactly; x = column parity checks the gather too.
+    ~17 GB of HBM."""
+    n_rows, n_cols = 1 << 20, 1 << 16
+    per_row = 2048 + 2                      # nnz = 2^20 * 2050 = 2^31 + 2^21
+    nnz = n_rows * per_row
+    assert nnz > 2 ** 31
+    Ap = torch.arange(n_rows + 1, dtype=torch.int64, device=DEV) * per_row
+    # columns: (row * 7 + position * 3) mod n_cols — cheap, deterministic, spread out
+    Aj = torch.empty(nnz, dtype=torch.int32, device=DEV)
+    step = 1 << 14
+    pos = torch.arange(per_row, dtype=torch.int64, device=DEV)[None, :] * 3
+    for r0 in range(0, n_rows, step):
+        rows = torch.arange(r0, r0 + step, dtype=torch.int64, device=DEV)[:, None] * 7
+        Aj[r0 * per_row:(r0 + step) * per_row] = ((rows + pos) % n_cols).reshape(-1).to(torch.int32)
+    Ax = torch.ones(nnz, dtype=torch.float32, device=DEV)
+    y = torch.full((n_rows,), float("nan"), device=DEV)
+    sp.spmv(kind, n_rows, n_cols, nnz, Ap, Aj, Ax, torch.ones(n_cols, device=DEV), y)
+    assert torch.equal(y, torch.full((n_rows,), float(per_row), device=DEV))
+    # x = 1 on even columns: row r sees position p at column (7r + 3p) mod 2^16, even iff (r + p) even
+    xe = (torch.arange(n_cols, device=DEV) % 2 == 0).to(torch.float32)
+    sp.spmv(kind, n_rows, n_cols, nnz, Ap, Aj, Ax, xe, y)
+    assert torch.equal(y, torch.full((n_rows,), float(per_row // 2), device=DEV))

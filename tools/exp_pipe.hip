@@ -219,11 +219,7 @@ __global__ __launch_bounds__(kBlock) void k_var(int n_rows, int n_cols, int nnz,
         return;
     }
     if (MODE == 0) {
-        __shared__ unsigned s_long_map[kMaxChunkRows / 32];
-        zero_long_map(s_long_map);
-        __syncthreads();
-        const ChunkScratch scr{s_long_map};
-        chunk_rows<T, R, int, float>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
+        // (the library body of that day; chunk_rows has since become the MODE 6 structure)
         return;
     }
     constexpr int VECS = kBlock / T;
@@ -322,7 +318,7 @@ int main() {
 #define RUN(T, R, MODE, RPC) { CK(hipMemset(y, 0, n * 4)); float ms = time_it([&] { k_var<T, R, MODE><<<n / RPC, 256>>>(n, n, (int)nnz, Ap, Aj, Ax, x, y, RPC, w); }); \
     printf("T=%d R=%d mode=%d rows/chunk=%5d : %7.3f ms  %7.1f GB/s  sum=%.6e\n", T, R, MODE, RPC, ms, bytes / ms / 1e6, checksum(y, n)); }
     for (int rep = 0; rep < 2; ++rep) {
-        RUN(8, 4, 0, 1024) RUN(8, 4, 6, 1024) RUN(8, 4, 17, 1024) RUN(8, 4, 48, 1024) RUN(8, 4, 112, 1024) RUN(8, 4, 50, 1024)
+        RUN(8, 4, 2, 1024) RUN(8, 4, 6, 1024) RUN(8, 4, 17, 1024) RUN(8, 4, 48, 1024) RUN(8, 4, 112, 1024) RUN(8, 4, 50, 1024)
     }
     return 0;
 }
