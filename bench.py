@@ -246,7 +246,7 @@ def main():
             "config": {"workload": "%s: %d rows/GPU x %d GPU, %d nnz/GPU, %s offsets, seeded"
                                    % (m.name, m.n_rows, world, m.nnz, "i32" if m.Ap.dtype == torch.int32 else "i64"),
                        "kind": kind, "lanes_per_row": info["lanes_per_row"], "grid_blocks": info["grid_blocks"],
-                       "kernels_per_step": info["n_kernels"], "x_window_elems": info["window_elems"], "reuse_structure": bool(args.reuse_structure),
+                       "kernels_per_step": info["n_kernels"], "x_window_elems": info["window_elems"], "x_window_segments": info["window_segments"], "reuse_structure": bool(args.reuse_structure),
                        "parallelism": ("row-block x%d, x replicated, allgatherv(y) over RCCL overlapped with the next "
                                        "step's SpMV" % world) if use_dist else "single GPU"},
             "achieved_hbm_gbps": achieved,

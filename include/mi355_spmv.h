@@ -126,6 +126,7 @@ typedef struct mi355_spmv_plan_info {
     int64_t scratch_bytes;    /* device scratch held by the plan                   */
     int32_t n_kernels;        /* kernels launched per execute                      */
     int32_t window_elems;     /* elements of x staged through LDS per workgroup (0 = none) */
+    int32_t window_segments;  /* 1 = one window; 2..4 = that many column bands staged side by side */
     char main_kernel[64];     /* substring of the dominant kernel's symbol name    */
 } mi355_spmv_plan_info;
 int mi355_spmv_plan_get_info(const mi355_spmv_plan* plan, mi355_spmv_plan_info* info);

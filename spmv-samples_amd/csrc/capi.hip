@@ -202,6 +202,7 @@ int mi355_spmv_plan_get_info(const mi355_spmv_plan* h, mi355_spmv_plan_info* inf
     info->scratch_bytes = (int64_t)p.scratch_bytes;
     info->n_kernels = p.n_kernels;
     info->window_elems = p.window_elems;
+    info->window_segments = p.window_elems > 0 ? (p.n_seg >= 2 ? p.n_seg : 1) : 0;
     snprintf(info->main_kernel, sizeof(info->main_kernel), "%s", p.main_kernel);
     return MI355_SPMV_OK;
 }

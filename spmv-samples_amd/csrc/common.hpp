@@ -59,6 +59,11 @@ struct Plan {
     bool probe_ok;
     int window_elems;           // LDS window of x per workgroup, in elements; 0 = no window
     bool window_from_band;      // place the window from band_lo/band_hi instead of sampling per chunk
+    // multi-band plan: up to 4 bands of (column - row) found by clustering the probe's samples
+    int n_seg;
+    int64_t seg_lo[4], seg_hi[4];
+    int probe_n;                 // sampled (column - row) offsets, sorted ascending
+    int64_t probe_off[8192];
     // dynamic rows
     int64_t rows_per_chunk;
     // scratch
@@ -83,6 +88,7 @@ int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x
 
 int probe_structure(Plan& p);
 int pick_window_elems(Plan& p, int64_t rows_per_workgroup);
+int64_t segment_rows_fit(const Plan& p);
 void shape_vector(Plan& p);
 void shape_merge(Plan& p);
 void shape_light(Plan& p);

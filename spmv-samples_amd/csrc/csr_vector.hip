@@ -20,11 +20,12 @@
 
 namespace mi355 {
 
-template <int T, int R, bool WINDOW, typename off_t, typename val_t>
+template <int T, int R, int NSEG, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void csr_vector_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, int32_t rows_per_chunk,
-    int32_t window_cap, BandHint hint) {
+    int32_t window_cap, BandHint hint, SegmentPlan segs) {
+    // NSEG: 0 = no window (plain gathers), 1 = one window of x in LDS, kMaxSegments = several bands
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2 * (kBlock / kWave)];
     const ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, rows_per_chunk);
@@ -32,8 +33,14 @@ __global__ __launch_bounds__(kBlock) void csr_vector_window_kernel(
     const int64_t rb = int64_t(chunk) * rows_per_chunk;
     const int64_t re = min(rb + rows_per_chunk, int64_t(n_rows));
     stage_chunk_bounds<off_t, val_t>(scr, rb, re, Ap);      // ordered before chunk_rows by the barrier below
-    const XWindow<val_t> win = stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
-    chunk_rows<T, R, WINDOW, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
+    if constexpr (NSEG > 1) {
+        const XWindowN<val_t> win = stage_x_segments<val_t>(rb, re, n_cols, x, scr.s_x, window_cap, segs);
+        chunk_rows<T, R, true, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
+    } else {
+        const XWindow<val_t> win =
+            stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
+        chunk_rows<T, R, NSEG == 1, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
+    }
 }
 
 template <int T, typename off_t, typename val_t>
@@ -67,6 +74,14 @@ void shape_vector(Plan& p) {
     if (p.grid_blocks < 1) p.grid_blocks = 1;
     p.n_tiles = p.grid_blocks;
     p.window_elems = pick_window_elems(p, p.rows_per_chunk);
+    if (const int64_t fit = segment_rows_fit(p)) {   // several bands: shrink the chunk until they all fit
+        const int64_t pass = int64_t(kBlock / p.lanes_per_row) * R;
+        if (fit < p.rows_per_chunk && fit >= pass) {
+            p.rows_per_chunk = fit / pass * pass;
+            p.grid_blocks = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
+            p.n_tiles = p.grid_blocks;
+        }
+    }
     p.n_kernels = 1;
     snprintf(p.main_kernel, sizeof(p.main_kernel), "csr_vector_window_kernel");
 }
@@ -79,13 +94,18 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
     const dim3 grid((unsigned)p.grid_blocks), block(kBlock);
     const off_t nnz = (off_t)p.nnz;
     const size_t lds = chunk_lds_bytes(p.window_elems, int(p.rows_per_chunk), sizeof(off_t), sizeof(val_t));
-#define MI355_VEC_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, (int32_t)p.rows_per_chunk, (int32_t)p.window_elems, hint
+    SegmentPlan segs;
+    segs.n = p.n_seg;
+    for (int i = 0; i < kMaxSegments; ++i) { segs.lo[i] = p.seg_lo[i]; segs.hi[i] = p.seg_hi[i]; }
+#define MI355_VEC_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, (int32_t)p.rows_per_chunk, (int32_t)p.window_elems, hint, segs
 #define MI355_VEC_CASE(TT)                                                                                   \
     case TT:                                                                                                 \
-        if (p.window_elems > 0)                                                                              \
-            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
+        if (p.window_elems > 0 && p.n_seg >= 2)                                                              \
+            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, kMaxSegments, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS); \
+        else if (p.window_elems > 0)                                                                         \
+            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, 1, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
         else                                                                                                 \
-            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS); \
+            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, 0, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
         break;
     switch (p.lanes_per_row) {
         MI355_VEC_CASE(2)

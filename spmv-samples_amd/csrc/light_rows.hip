@@ -46,11 +46,12 @@ __device__ __forceinline__ unsigned long long wave_broadcast_u64(unsigned long l
     return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
-template <int T, int R, bool WINDOW, typename off_t, typename val_t>
+template <int T, int R, int NSEG, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
-    unsigned long long* __restrict__ counters, int32_t rows_per_chunk, int32_t window_cap, BandHint hint) {
+    unsigned long long* __restrict__ counters, int32_t rows_per_chunk, int32_t window_cap, BandHint hint,
+    SegmentPlan segs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2 * (kBlock / kWave)];
     __shared__ unsigned long long s_got;
@@ -70,9 +71,15 @@ __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
             const int64_t chunk_end = min(chunk_begin + rows_per_chunk, shard_end);
             // (stage_x_window's barriers also order this read of s_got before the next write)
             stage_chunk_bounds<off_t, val_t>(scr, chunk_begin, chunk_end, Ap);   // before the barrier below
-            const XWindow<val_t> win = stage_x_window<off_t, val_t>(
-                chunk_begin, chunk_end, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
-            chunk_rows<T, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+            if constexpr (NSEG > 1) {
+                const XWindowN<val_t> win =
+                    stage_x_segments<val_t>(chunk_begin, chunk_end, n_cols, x, scr.s_x, window_cap, segs);
+                chunk_rows<T, R, true, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+            } else {
+                const XWindow<val_t> win = stage_x_window<off_t, val_t>(
+                    chunk_begin, chunk_end, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
+                chunk_rows<T, R, NSEG == 1, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+            }
             __syncthreads();  // every wave is done with the window before it is refilled
         }
         __syncthreads();      // s_got read by all before the next shard's dequeue overwrites it
@@ -135,6 +142,13 @@ void shape_light(Plan& p) {
     p.rows_per_chunk = chunk;
     p.n_tiles = (int64_t(p.n_rows) + chunk - 1) / chunk;
     p.window_elems = pick_window_elems(p, chunk);
+    if (const int64_t fit = segment_rows_fit(p)) {   // several bands: shrink the chunk until they all fit
+        if (fit < chunk && fit >= pass) {
+            chunk = fit / pass * pass;
+            p.rows_per_chunk = chunk;
+            p.n_tiles = (int64_t(p.n_rows) + chunk - 1) / chunk;
+        }
+    }
     // persistent grid: 4 workgroups per CU with the 36 KB window, 5 without (VGPR-bound),
     // fewer for small inputs
     int64_t blocks = p.n_tiles;
@@ -156,13 +170,18 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
     const off_t nnz = (off_t)p.nnz;
     const int32_t chunk = (int32_t)p.rows_per_chunk;
     const size_t lds = chunk_lds_bytes(p.window_elems, chunk, sizeof(off_t), sizeof(val_t));
-#define MI355_LIGHT_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, p.counters, chunk, (int32_t)p.window_elems, hint
+    SegmentPlan segs;
+    segs.n = p.n_seg;
+    for (int i = 0; i < kMaxSegments; ++i) { segs.lo[i] = p.seg_lo[i]; segs.hi[i] = p.seg_hi[i]; }
+#define MI355_LIGHT_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, p.counters, chunk, (int32_t)p.window_elems, hint, segs
 #define MI355_LIGHT_CASE(TT)                                                                                   \
     case TT:                                                                                                   \
-        if (p.window_elems > 0)                                                                                \
-            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
+        if (p.window_elems > 0 && p.n_seg >= 2)                                                                \
+            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, kMaxSegments, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS); \
+        else if (p.window_elems > 0)                                                                           \
+            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, 1, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
         else                                                                                                   \
-            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS); \
+            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, 0, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
         break;
     switch (p.lanes_per_row) {
         MI355_LIGHT_CASE(2)

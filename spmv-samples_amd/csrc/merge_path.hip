@@ -329,6 +329,7 @@ void shape_merge(Plan& p) {
         const int64_t mean1 = 1 + (p.n_rows > 0 ? p.nnz / p.n_rows : 0);
         const int64_t rows_per_run = tps * p.tile_items / mean1 + 1;
         p.window_elems = (tps * p.tile_items >= 8192) ? pick_window_elems(p, rows_per_run) : 0;
+        if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }   // several bands: this kind keeps to global gathers
     }
     p.n_kernels = p.n_super > 1 ? 3 : 2;
     p.coords_valid = false;

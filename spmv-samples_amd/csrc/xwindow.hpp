@@ -37,6 +37,39 @@ struct XWindow {
     const val_t* s_x;   // LDS copy of x[lo, lo+len)
     int32_t lo;
     int32_t len;
+    // LDS index of column `col` (0 when it is outside the window); returns whether it is inside
+    __device__ __forceinline__ bool find(int32_t col, unsigned& idx) const {
+        const unsigned rel = unsigned(col - lo);
+        const bool in = rel < unsigned(len);
+        idx = in ? rel : 0u;
+        return in;
+    }
+};
+
+// Several windows at once, for matrices whose columns sit in a few far-apart bands (a 3-D
+// stencil: the planes k-1, k, k+1 are ~nx*ny columns apart; one window cannot span them but
+// three narrow ones hold everything).  Segment s holds x[lo[s], lo[s]+len[s]) at s_x + off[s].
+constexpr int kMaxSegments = 4;
+struct SegmentPlan {                 // bands [lo, hi] of (column - row), from the plan's probe
+    int n;
+    int64_t lo[kMaxSegments], hi[kMaxSegments];
+};
+template <typename val_t>
+struct XWindowN {
+    const val_t* s_x;
+    int32_t lo[kMaxSegments], len[kMaxSegments], off[kMaxSegments];
+    __device__ __forceinline__ bool find(int32_t col, unsigned& idx) const {
+        bool in = false;
+        idx = 0u;
+#pragma unroll
+        for (int s = 0; s < kMaxSegments; ++s) {
+            const unsigned rel = unsigned(col - lo[s]);
+            const bool ins = rel < unsigned(len[s]);
+            idx = ins ? unsigned(off[s]) + rel : idx;
+            in |= ins;
+        }
+        return in;
+    }
 };
 
 __device__ __forceinline__ int wave_min(int v) {
@@ -147,6 +180,45 @@ __device__ __forceinline__ XWindow<val_t> stage_x_window(int64_t rb, int64_t re,
     return win;
 }
 
+// Workgroup-wide: stage the segments of `plan` for rows [rb, re) (capacity `cap` elements in
+// total, later segments are cut when it runs out).  Ends with a barrier.
+template <typename val_t>
+__device__ __forceinline__ XWindowN<val_t> stage_x_segments(int64_t rb, int64_t re, int32_t n_cols,
+                                                            const val_t* __restrict__ x, val_t* s_x,
+                                                            int32_t cap, const SegmentPlan& plan) {
+    constexpr int PER16 = 16 / int(sizeof(val_t));
+    using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
+    const int tid = threadIdx.x;
+    XWindowN<val_t> win;
+    win.s_x = s_x;
+    int off = 0;
+#pragma unroll
+    for (int s = 0; s < kMaxSegments; ++s) {
+        int lo = 0, len = 0;
+        if (s < plan.n && re > rb && off < cap && n_cols > 0) {
+            int64_t l = rb + plan.lo[s], h = re - 1 + plan.hi[s];
+            l = l < 0 ? 0 : l;
+            h = h >= n_cols ? int64_t(n_cols) - 1 : h;
+            if (h >= l) {
+                lo = int(l) & ~(PER16 - 1);
+                len = int(h) + 1 - lo;
+                if (off + len > cap) len = cap - off;
+            }
+        }
+        win.lo[s] = lo;
+        win.len[s] = len;
+        win.off[s] = off;
+        int full = (min(lo + len, n_cols & ~(PER16 - 1)) - lo) / PER16;   // whole 16-byte groups inside x
+        if (full < 0) full = 0;
+        for (int g = tid; g < full; g += kBlock)
+            *reinterpret_cast<v16*>(s_x + off + g * PER16) = *reinterpret_cast<const v16*>(x + lo + g * PER16);
+        for (int i = full * PER16 + tid; i < len; i += kBlock) s_x[off + i] = x[lo + i];
+        off += (len + PER16 - 1) & ~(PER16 - 1);
+    }
+    __syncthreads();
+    return win;
+}
+
 // One value of x: from the window when the column is inside it, else from global.
 template <typename val_t>
 __device__ __forceinline__ val_t window_gather(const XWindow<val_t>& win, const val_t* __restrict__ x,
@@ -237,11 +309,11 @@ __device__ __forceinline__ void load_group(off_t j, off_t nnz, const int32_t* __
 //    sums every marked row with a whole 64-lane wave, the four waves taking rows in turn.
 // All kBlock threads must call (wave-wide shuffles and barriers inside); the caller has
 // run stage_chunk_bounds + a barrier.
-template <int T, int R, bool WINDOW, typename off_t, typename val_t>
+template <int T, int R, bool WINDOW, typename off_t, typename val_t, typename Win>
 __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_end, off_t nnz,
                                            const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
                                            const val_t* __restrict__ Ax, const val_t* __restrict__ x,
-                                           val_t* __restrict__ y, const XWindow<val_t>& win,
+                                           val_t* __restrict__ y, const Win& win,
                                            const ChunkScratch<off_t, val_t>& scr) {
     using v4 = typename Vec4<val_t>::type;
     constexpr int VECS = kBlock / T;
@@ -287,9 +359,9 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
             for (int e = 0; e < 4; ++e) {
                 const off_t k = j + e;
                 const bool valid = (k >= lo) && (k < hi);
-                const unsigned rel = unsigned(c[e] - win.lo);
-                const bool in = rel < unsigned(win.len);
-                const val_t xv = win.s_x[in ? rel : 0u];
+                unsigned idx;
+                const bool in = win.find(c[e], idx);
+                const val_t xv = win.s_x[idx];
                 sum = (valid && in) ? (sum + a[e] * xv) : sum;
                 need[e] = valid && !in;
                 any_need |= need[e];
