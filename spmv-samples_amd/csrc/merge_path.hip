@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
     const int32_t* __restrict__ tile_row, const int64_t* __restrict__ tile_nnz,
     int32_t* __restrict__ carry_row, val_t* __restrict__ carry_val, int64_t n_tiles, int32_t tiles_per_super,
-    int32_t window_cap) {
+    int32_t window_cap, BandHint hint) {
     constexpr int G = IPT / 4;
     using v4 = typename Vec4<val_t>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window_cap values of x
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     const int64_t row_lo = tile_row[first];
     const int64_t row_hi = min(int64_t(tile_row[last]) + 1, int64_t(n_rows));
     const XWindow<val_t> win =
-        stage_x_window<off_t, val_t>(row_lo, row_hi, n_cols, Ap, Aj, x, s_x, window_cap, s_red);
+        stage_x_window<off_t, val_t>(row_lo, row_hi, n_cols, Ap, Aj, x, s_x, window_cap, s_red, hint);
 
     int x0 = tile_row[first], x1 = tile_row[first + 1];
     int64_t y0 = tile_nnz[first], y1 = tile_nnz[first + 1];
@@ -351,11 +351,12 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
     }
     const int32_t cap = (aligned && p.nnz >= 4) ? (int32_t)p.window_elems : 0;
     const size_t dyn = size_t(cap) * sizeof(val_t);
+    const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
     const dim3 grid((unsigned)p.n_super), block(kBlock);
 #define MI355_MERGE_LAUNCH(IPT_, VEC_, WIN_)                                                                  \
     hipLaunchKernelGGL((merge_tile_kernel<IPT_, VEC_, WIN_, off_t, val_t>), grid, block, dyn, s, p.n_rows,     \
                        p.n_cols, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz, p.carry_row,              \
-                       static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super, cap)
+                       static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super, cap, hint)
     const bool vec = aligned && p.nnz >= 4;
     if (p.elems_per_lane == 16) {
         if (!vec) MI355_MERGE_LAUNCH(16, false, false);

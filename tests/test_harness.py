@@ -83,3 +83,25 @@ def test_unknown_kind_and_unit_flag(exe):
     assert re.search(r"\[hip_vector  \] sum: +0\.000000  avg: +0\.000000", r.stdout)       # integer-valued: exact
     r = run(exe, path, "cusparse")
     assert r.returncode == 1 and 'SpMV kind "cusparse" is NOT SUPPROT' in r.stderr        # spmv.h:46-47
+
+
+@pytest.mark.gpu
+def test_harness_on_a_generated_banded_file(exe, tmp_path):
+    """End to end on a file large enough for the parallel parser to cut it into many chunks
+    (40 000 rows x 32 nonzeros, ~21 MB of text): loader -> CSR -> three kinds -> delta table."""
+    import numpy as np
+    n, per_row, w = 40000, 32, 600
+    rng = np.random.RandomState(12)
+    rows = np.repeat(np.arange(n), per_row)
+    lo = np.clip(np.arange(n) - w, 0, n - 2 * w - 1)
+    cols = (lo[:, None] + np.sort(rng.randint(0, 2 * w, size=(n, per_row)), axis=1)).reshape(-1)
+    vals = rng.randint(-4, 5, size=n * per_row)            # small integers: every kind must be exact
+    path = tmp_path / "band.mtx"
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate integer general\n%d %d %d\n" % (n, n, n * per_row))
+        np.savetxt(f, np.stack([rows + 1, cols + 1, vals], axis=1), fmt="%d")
+    r = run(exe, str(path), "hip_vector", "hip_merge", "hip_light", "--iters", "20")
+    assert r.returncode == 0, r.stderr
+    assert "n_rows: 40000  n_cols: 40000  nnz: 1280000" in r.stdout
+    for k in ("hip_vector", "hip_merge", "hip_light"):
+        assert re.search(r"^\[%-12s\] sum: +0\.000000  avg: +0\.000000$" % k, r.stdout, re.M), r.stdout
