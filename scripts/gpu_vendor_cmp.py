@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Comparison column only (NOT part of the engine): the vendor library's CSR SpMV, reached through
+torch.sparse (hipSPARSE/rocSPARSE underneath), timed on the same matrices as bench.py.
+The reference's `cusparse` kind (include/spmv/cusparse.cuh) is the analogue on NVIDIA."""
+import json
+import sys
+import os
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g
+
+sp = g.load_package()
+dev = torch.device("cuda:0")
+out = {}
+for w in (sys.argv[1:] or ["s32-band", "c2-cant", "c3-webgoogle"]):
+    m = sp.synth.workload(w, dev)
+    if m.Ap.dtype != m.Aj.dtype:
+        # torch.sparse_csr_tensor does not validate index dtypes by default; int64 crow + int32 col
+        # indices faulted inside the vendor path (MI355X, torch 2.10/ROCm 7.0): never run that
+        print(w, "skipped: mixed index dtypes are not safe to hand to torch.sparse")
+        continue
+    x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, dev)
+    A = torch.sparse_csr_tensor(m.Ap, m.Aj, m.Ax, size=(m.n_rows, m.n_cols))
+    y = A @ x
+    # our engine on the same operands, for the cross-check and the side-by-side time
+    res = {}
+    y2 = torch.empty_like(y)
+    for kind in ("vector", "merge", "light"):
+        p = sp.Plan(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype)
+        for _ in range(5):
+            p.execute(m.Ax, x, y2)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(30):
+            p.execute(m.Ax, x, y2)
+        b.record()
+        torch.cuda.synchronize()
+        res[kind] = a.elapsed_time(b) / 30 * 1e3
+        p.destroy()
+    err = float((y2 - y).abs().max() / (y.abs().max() + 1e-30))
+    for _ in range(5):
+        y = A @ x
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(30):
+        y = A @ x
+    b.record()
+    torch.cuda.synchronize()
+    t = a.elapsed_time(b) / 30 * 1e3
+    out[w] = {"vendor_torch_sparse_us": t, "ours_us": res, "rel_maxdiff_vs_vendor": err,
+              "algorithmic_GBps_vendor": m.algorithmic_bytes() / t / 1e3}
+    print(w, json.dumps(out[w]), flush=True)
+    del A, m, x, y, y2
+    torch.cuda.empty_cache()
