@@ -63,6 +63,16 @@ enum { MI355_KIND_VECTOR = 0, MI355_KIND_MERGE = 1, MI355_KIND_LIGHT = 2, MI355_
 enum { MI355_OFF_I32 = 0, MI355_OFF_I64 = 1 };
 enum { MI355_VAL_F32 = 0, MI355_VAL_F64 = 1 };
 
+/* semirings of the generalized merge kind.  The reference's
+ * SpMV_merge_based_generalized takes a functor_t with initialize / combine / reduce
+ * (include/spmv/merge_genl/merge_genl.cuh:19-38; CPU twin include/spmv/cpu_navie.hpp:20-34)
+ * and ships (+, *); a C ABI enumerates them instead:
+ *   PLUS_TIMES  y[r] = sum_k  Ax[k] * x[Aj[k]]           (identity 0)      — every other entry point
+ *   MIN_PLUS    y[r] = min_k (Ax[k] + x[Aj[k]])          (identity +inf)   — shortest-path relaxation
+ *   MAX_TIMES   y[r] = max_k (Ax[k] * x[Aj[k]])          (identity -inf)   — or-and on {0,1}, widest path */
+enum { MI355_SEMIRING_PLUS_TIMES = 0, MI355_SEMIRING_MIN_PLUS = 1, MI355_SEMIRING_MAX_TIMES = 2,
+       MI355_SEMIRING_COUNT = 3 };
+
 /* plan flags */
 enum {
     MI355_PLAN_DEFAULT = 0,
@@ -93,6 +103,17 @@ MI355_SPMV_DECLARE_KIND(vector) /* replaces SpMV_cusp_warp_reduce  cusp_warp_red
 MI355_SPMV_DECLARE_KIND(merge)  /* replaces SpMV_merge_based[_generalized] merge_based.cuh:22, merge_genl.cuh:41 */
 MI355_SPMV_DECLARE_KIND(light)  /* replaces SpMV_light_vector/_warp  LightSpMV.cuh:379, :400 */
 
+/* generalized merge-path SpMV: the reference's SpMV_merge_based_generalized
+ * (include/spmv/merge_genl/merge_genl.cuh:41-79) with the semiring as an argument.  */
+#define MI355_SPMV_DECLARE_GENL(SUF, OFF, VAL)                                                  \
+    int mi355_spmv_merge_genl_##SUF(int semiring, int32_t n_rows, int32_t n_cols, OFF nnz,      \
+                                    const OFF* Ap, const int32_t* Aj, const VAL* Ax,            \
+                                    const VAL* x, VAL* y, void* stream);
+MI355_SPMV_DECLARE_GENL(i32_f32, int32_t, float)
+MI355_SPMV_DECLARE_GENL(i32_f64, int32_t, double)
+MI355_SPMV_DECLARE_GENL(i64_f32, int64_t, float)
+MI355_SPMV_DECLARE_GENL(i64_f64, int64_t, double)
+
 /* ---- plan entry points -----------------------------------------------------
  * The reference re-creates scratch on every call (quirks 7-9 of SURVEY.md §2c);
  * a plan keeps scratch and launch shapes across the timing loop of main.cu:102-113.
@@ -107,6 +128,8 @@ int mi355_spmv_plan_create(mi355_spmv_plan** plan, int kind, int off_type, int v
 int mi355_spmv_plan_execute(mi355_spmv_plan* plan, const void* Ax, const void* x, void* y,
                             void* stream);
 int mi355_spmv_plan_destroy(mi355_spmv_plan* plan);
+/* MERGE plans only (ENOTSUP otherwise): choose the semiring of the following executes.  */
+int mi355_spmv_plan_set_semiring(mi355_spmv_plan* plan, int semiring);
 /* Block the host until `stream` has drained (hipStreamSynchronize), so that a
  * host-only C++ caller can bracket Timer::kernel_stop() the way the reference's
  * kinds do with cudaDeviceSynchronize() (cusp_warp_reduce.cuh:131) without

@@ -62,6 +62,15 @@ class Oracle:
         getattr(self.lib, f"oracle_spmv_serial_{o}_{v}")(C.c_int32(n), _p(Ap), _p(Aj), _p(Ax), _p(x), _p(y))
         return y
 
+    def spmv_genl_serial(self, semiring, Ap, Aj, Ax, x):
+        """Generalized serial SpMV (cpu_navie.hpp:20-34); semiring 0 = (+,*), 1 = (min,+), 2 = (max,*)."""
+        n = self._check(Ap, Aj, Ax, x)
+        o, v = suffix(Ap, Ax)
+        y = np.empty(n, dtype=Ax.dtype)
+        getattr(self.lib, f"oracle_spmv_genl_serial_{o}_{v}")(
+            C.c_int(semiring), C.c_int32(n), _p(Ap), _p(Aj), _p(Ax), _p(x), _p(y))
+        return y
+
     def spmv_parallel(self, Ap, Aj, Ax, x, n_threads):
         n = self._check(Ap, Aj, Ax, x)
         o, v = suffix(Ap, Ax)
@@ -157,6 +166,15 @@ class Ref:
         getattr(self.lib, f"ref_copy_{s}")(h, _p(Ap), _p(Aj), _p(Ax))
         getattr(self.lib, f"ref_free_{s}")(h)
         return nr.value, nc.value, Ap, Aj, Ax
+
+    def spmv_genl_cpu(self, semiring, n_cols, Ap, Aj, Ax, x):
+        o, v = suffix(Ap, Ax)
+        n = len(Ap) - 1
+        y = np.empty(n, dtype=Ax.dtype)
+        nnz = _OFF[o][1](int(Ap[-1]))
+        getattr(self.lib, f"ref_spmv_genl_cpu_{o}_{v}")(
+            C.c_int(semiring), C.c_int(n), C.c_int(n_cols), nnz, _p(Ap), _p(Aj), _p(Ax), _p(x), _p(y))
+        return y
 
     def spmv_cpu(self, n_cols, Ap, Aj, Ax, x):
         o, v = suffix(Ap, Ax)

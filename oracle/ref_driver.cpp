@@ -6,6 +6,7 @@
 // copied into this repository; this file only instantiates and calls:
 //   LoadCoo / ToCsr      include/load.hpp:268-408, :420-474
 //   SpMV_cpu_navie       include/spmv/cpu_navie.hpp:5-17
+//   SpMV_genl_cpu_navie  include/spmv/cpu_navie.hpp:20-34 (with the functors defined below)
 // The two standard headers below come first because load.hpp uses std::cerr and
 // std::numeric_limits without including them (load.hpp:279, :302).
 //
@@ -22,6 +23,25 @@
 #include "spmv/cpu_navie.hpp"
 
 namespace {
+// functor_t instances for the reference's SpMV_genl_cpu_navie<functor_t> (cpu_navie.hpp:20-34).
+// The reference's only instance, MergeFunctor (merge_genl.cuh:19-38: initialize 0, combine
+// nonzero*x, reduce a+b), sits in a CUDA/CUB header and cannot be included; PlusTimes restates
+// its three one-liners, the other two are the semirings the C ABI adds.
+template <typename V> struct PlusTimes {
+    static V initialize() { return V(0); }
+    static V combine(V a, V x) { return a * x; }
+    static V reduce(V u, V v) { return u + v; }
+};
+template <typename V> struct MinPlus {
+    static V initialize() { return std::numeric_limits<V>::infinity(); }
+    static V combine(V a, V x) { return a + x; }
+    static V reduce(V u, V v) { return v < u ? v : u; }
+};
+template <typename V> struct MaxTimes {
+    static V initialize() { return -std::numeric_limits<V>::infinity(); }
+    static V combine(V a, V x) { return a * x; }
+    static V reduce(V u, V v) { return u < v ? v : u; }
+};
 template <typename off_t, typename val_t>
 struct Held {
     csr_t<int, off_t, val_t> csr;
@@ -53,6 +73,15 @@ extern "C" {
         memcpy(Ax, h->csr.nonzero_values.data(), h->csr.nonzero_values.size() * sizeof(VAL));  \
     }                                                                                          \
     void ref_free_##SUF(void* hp) { delete static_cast<Held<OFF, VAL>*>(hp); }                 \
+    void ref_spmv_genl_cpu_##SUF(int semiring, int n_rows, int n_cols, OFF nnz, const OFF* Ap,  \
+                                 const int* Aj, const VAL* Ax, const VAL* x, VAL* y) {         \
+        if (semiring == 0)                                                                     \
+            SpMV_genl_cpu_navie<PlusTimes<VAL>, int, OFF, VAL, VAL, VAL>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y); \
+        else if (semiring == 1)                                                                \
+            SpMV_genl_cpu_navie<MinPlus<VAL>, int, OFF, VAL, VAL, VAL>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);   \
+        else                                                                                   \
+            SpMV_genl_cpu_navie<MaxTimes<VAL>, int, OFF, VAL, VAL, VAL>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);  \
+    }                                                                                          \
     void ref_spmv_cpu_##SUF(int n_rows, int n_cols, OFF nnz, const OFF* Ap, const int* Aj,     \
                             const VAL* Ax, const VAL* x, VAL* y) {                             \
         SpMV_cpu_navie<int, OFF, VAL, VAL, VAL>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);        \

@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <thread>
 #include <vector>
@@ -47,6 +48,24 @@ void spmv_serial(int32_t row_begin, int32_t row_end, const off_t* Ap,
         val_t sum = val_t(0);
         for (off_t k = Ap[row]; k < Ap[row + 1]; ++k) {
             sum += Ax[k] * x[Aj[k]];
+        }
+        y[row] = sum;
+    }
+}
+
+// Generalized serial SpMV — restates include/spmv/cpu_navie.hpp:20-34:
+//   sum = functor::initialize(); sum = functor::reduce(sum, functor::combine(Ax[k], x[Aj[k]])); y[row] = sum
+// with the semirings the C ABI enumerates (include/mi355_spmv.h): 0 = (+, *), 1 = (min, +), 2 = (max, *).
+template <typename off_t, typename val_t>
+void spmv_genl_serial(int semiring, int32_t n_rows, const off_t* Ap, const int32_t* Aj, const val_t* Ax,
+                      const val_t* x, val_t* y) {
+    const val_t inf = std::numeric_limits<val_t>::infinity();
+    for (int32_t row = 0; row < n_rows; ++row) {
+        val_t sum = semiring == 0 ? val_t(0) : (semiring == 1 ? inf : -inf);
+        for (off_t k = Ap[row]; k < Ap[row + 1]; ++k) {
+            if (semiring == 0) sum = sum + Ax[k] * x[Aj[k]];
+            else if (semiring == 1) { const val_t v = Ax[k] + x[Aj[k]]; sum = v < sum ? v : sum; }
+            else { const val_t v = Ax[k] * x[Aj[k]]; sum = sum < v ? v : sum; }
         }
         y[row] = sum;
     }
@@ -483,6 +502,10 @@ extern "C" {
     void oracle_spmv_serial_##SUF(int32_t n_rows, const OFF* Ap, const int32_t* Aj,            \
                                   const VAL* Ax, const VAL* x, VAL* y) {                       \
         spmv_serial<OFF, VAL>(0, n_rows, Ap, Aj, Ax, x, y);                                    \
+    }                                                                                          \
+    void oracle_spmv_genl_serial_##SUF(int semiring, int32_t n_rows, const OFF* Ap, const int32_t* Aj,  \
+                                       const VAL* Ax, const VAL* x, VAL* y) {                  \
+        spmv_genl_serial<OFF, VAL>(semiring, n_rows, Ap, Aj, Ax, x, y);                        \
     }                                                                                          \
     void oracle_spmv_parallel_##SUF(int32_t n_rows, const OFF* Ap, const int32_t* Aj,          \
                                     const VAL* Ax, const VAL* x, VAL* y, int n_threads) {      \

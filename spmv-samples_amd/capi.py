@@ -21,9 +21,12 @@ LABELS = {"hip_vector": "vector", "hip_merge": "merge", "hip_light": "light"}
 OFF_TYPES = {torch.int32: (0, "i32"), torch.int64: (1, "i64")}
 VAL_TYPES = {torch.float32: (0, "f32"), torch.float64: (1, "f64")}
 PLAN_REUSE_STRUCTURE = 1
+SEMIRINGS = {"plus_times": 0, "min_plus": 1, "max_times": 2}
 
 EXPORTS = (
     ["mi355_spmv_%s_%s_%s" % (k, o, v) for k in KINDS for o in ("i32", "i64") for v in ("f32", "f64")]
+    + ["mi355_spmv_merge_genl_%s_%s" % (o, v) for o in ("i32", "i64") for v in ("f32", "f64")]
+    + ["mi355_spmv_plan_set_semiring"]
     + ["mi355_spmv_plan_create", "mi355_spmv_plan_execute", "mi355_spmv_plan_destroy",
        "mi355_spmv_plan_get_info", "mi355_spmv_stream_synchronize", "mi355_spmv_plan_merge_coords", "mi355_spmv_version",
        "mi355_spmv_status_string", "mi355_spmv_last_error", "mi355_spmv_device_count"]
@@ -61,6 +64,7 @@ def lib():
                                              C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
         L.mi355_spmv_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi355_spmv_plan_destroy.argtypes = [C.c_void_p]
+        L.mi355_spmv_plan_set_semiring.argtypes = [C.c_void_p, C.c_int]
         L.mi355_spmv_plan_get_info.argtypes = [C.c_void_p, C.POINTER(PlanInfo)]
         L.mi355_spmv_plan_merge_coords.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -108,6 +112,24 @@ def spmv(kind, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream=None):
     return y
 
 
+def spmv_genl(semiring, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream=None):
+    """Generalized merge-path SpMV: the reference's SpMV_merge_based_generalized
+    (include/spmv/merge_genl/merge_genl.cuh:41-79) with the semiring as an argument."""
+    sr = SEMIRINGS[semiring] if isinstance(semiring, str) else int(semiring)
+    _require_device(Ap, Aj, Ax, x, y)
+    if Aj.dtype != torch.int32 or Ax.dtype != x.dtype or Ax.dtype != y.dtype:
+        raise TypeError("Aj must be int32 and Ax, x, y one value type")
+    o = OFF_TYPES[Ap.dtype][1]
+    v = VAL_TYPES[Ax.dtype][1]
+    fn = getattr(lib(), "mi355_spmv_merge_genl_%s_%s" % (o, v))
+    nnz_c = C.c_int32(nnz) if o == "i32" else C.c_int64(nnz)
+    st = fn(C.c_int(sr), C.c_int32(n_rows), C.c_int32(n_cols), nnz_c, C.c_void_p(Ap.data_ptr()),
+            C.c_void_p(Aj.data_ptr()), C.c_void_p(Ax.data_ptr()), C.c_void_p(x.data_ptr()),
+            C.c_void_p(y.data_ptr()), _stream_ptr(stream))
+    _check(st, "mi355_spmv_merge_genl_%s_%s" % (o, v))
+    return y
+
+
 class Plan:
     """Scratch + launch shapes kept across calls (mi355_spmv_plan_*).  Holds
     references to Ap and Aj so they outlive the plan."""
@@ -138,6 +160,10 @@ class Plan:
                                            C.c_void_p(y.data_ptr()), _stream_ptr(stream))
         _check(st, "mi355_spmv_plan_execute")
         return y
+
+    def set_semiring(self, semiring):
+        sr = SEMIRINGS[semiring] if isinstance(semiring, str) else int(semiring)
+        _check(lib().mi355_spmv_plan_set_semiring(self._h, C.c_int(sr)), "mi355_spmv_plan_set_semiring")
 
     def info(self):
         pi = PlanInfo()

@@ -62,11 +62,16 @@ static int execute_typed(Plan& p, const void* Ax, const void* x, void* y, hipStr
 }
 
 static int one_shot(int kind, int off_type, int val_type, int32_t n_rows, int32_t n_cols, int64_t nnz,
-                    const void* Ap, const int32_t* Aj, const void* Ax, const void* x, void* y, void* stream) {
+                    const void* Ap, const int32_t* Aj, const void* Ax, const void* x, void* y, void* stream,
+                    int semiring = MI355_SEMIRING_PLUS_TIMES) {
     mi355_spmv_plan* plan = nullptr;
     int st = mi355_spmv_plan_create(&plan, kind, off_type, val_type, n_rows, n_cols, nnz, Ap, Aj,
                                     MI355_PLAN_DEFAULT);
     if (st != MI355_SPMV_OK) return st;
+    if (semiring != MI355_SEMIRING_PLUS_TIMES) {
+        st = mi355_spmv_plan_set_semiring(plan, semiring);
+        if (st != MI355_SPMV_OK) { mi355_spmv_plan_destroy(plan); return st; }
+    }
     st = mi355_spmv_plan_execute(plan, Ax, x, y, stream);
     if (st == MI355_SPMV_OK) {
         hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
@@ -181,6 +186,18 @@ int mi355_spmv_plan_destroy(mi355_spmv_plan* h) {
     return st;
 }
 
+int mi355_spmv_plan_set_semiring(mi355_spmv_plan* h, int semiring) {
+    g_err[0] = 0;
+    if (!h) { set_error("plan_set_semiring: null plan"); return MI355_SPMV_EINVAL; }
+    if (semiring < 0 || semiring >= MI355_SEMIRING_COUNT) { set_error("plan_set_semiring: unknown semiring %d", semiring); return MI355_SPMV_EINVAL; }
+    if (h->p.kind != MI355_KIND_MERGE && semiring != MI355_SEMIRING_PLUS_TIMES) {
+        set_error("plan_set_semiring: only the merge kind is generalized (as in the reference)");
+        return MI355_SPMV_ENOTSUP;
+    }
+    h->p.semiring = semiring;
+    return MI355_SPMV_OK;
+}
+
 int mi355_spmv_stream_synchronize(void* stream) {
     g_err[0] = 0;
     MI355_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
@@ -234,6 +251,20 @@ int mi355_spmv_plan_merge_coords(mi355_spmv_plan* h, int64_t* tile_row, int64_t*
     MI355_SPMV_DEFINE(KIND, KINDENUM, i32_f64, int32_t, MI355_OFF_I32, double, MI355_VAL_F64)  \
     MI355_SPMV_DEFINE(KIND, KINDENUM, i64_f32, int64_t, MI355_OFF_I64, float, MI355_VAL_F32)   \
     MI355_SPMV_DEFINE(KIND, KINDENUM, i64_f64, int64_t, MI355_OFF_I64, double, MI355_VAL_F64)
+
+#define MI355_SPMV_DEFINE_GENL(SUF, OFF, OFFENUM, VAL, VALENUM)                                          \
+    int mi355_spmv_merge_genl_##SUF(int semiring, int32_t n_rows, int32_t n_cols, OFF nnz, const OFF* Ap, \
+                                    const int32_t* Aj, const VAL* Ax, const VAL* x, VAL* y, void* st) {  \
+        if (semiring < 0 || semiring >= MI355_SEMIRING_COUNT) {                                           \
+            set_error("merge_genl: unknown semiring %d", semiring);                                       \
+            return MI355_SPMV_EINVAL;                                                                     \
+        }                                                                                                 \
+        return one_shot(MI355_KIND_MERGE, OFFENUM, VALENUM, n_rows, n_cols, (int64_t)nnz, Ap, Aj, Ax, x, y, st, semiring); \
+    }
+MI355_SPMV_DEFINE_GENL(i32_f32, int32_t, MI355_OFF_I32, float, MI355_VAL_F32)
+MI355_SPMV_DEFINE_GENL(i32_f64, int32_t, MI355_OFF_I32, double, MI355_VAL_F64)
+MI355_SPMV_DEFINE_GENL(i64_f32, int64_t, MI355_OFF_I64, float, MI355_VAL_F32)
+MI355_SPMV_DEFINE_GENL(i64_f64, int64_t, MI355_OFF_I64, double, MI355_VAL_F64)
 
 MI355_SPMV_DEFINE_KIND(vector, MI355_KIND_VECTOR)
 MI355_SPMV_DEFINE_KIND(merge, MI355_KIND_MERGE)

@@ -54,6 +54,7 @@ struct Plan {
     int64_t tile_items, n_tiles;
     int64_t tiles_per_super, n_super;   // consecutive tiles one workgroup walks; number of such groups
     bool coords_valid;
+    int semiring;               // MERGE: MI355_SEMIRING_* (0 = plus-times)
     // structure probe (plan creation): band of (column - row) seen on sampled rows
     int64_t band_lo, band_hi;   // valid when probe_ok
     bool probe_ok;

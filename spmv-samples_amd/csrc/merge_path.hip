@@ -44,6 +44,7 @@
 // :572-597) needs no special case here.
 
 #include <climits>
+#include <cmath>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -55,6 +56,29 @@ namespace mi355 {
 // merge items per thread (IPT) is 8 or 16; a tile has kBlock * IPT - 4 items so that
 // (tile nnz + 3) / 4 <= kBlock * IPT / 4 sixteen-byte groups, IPT / 4 per thread
 constexpr int kMergeSuperItems = 32768;                   // items one workgroup walks at most
+
+// ---- semirings --------------------------------------------------------------
+// The reference's generalized merge kind takes a functor with initialize / combine / reduce
+// (include/spmv/merge_genl/merge_genl.cuh:19-38, agent_spmv_orig.cuh:98-124; CPU twin
+// include/spmv/cpu_navie.hpp:20-34) and ships one instance, (+, *).  A C ABI cannot take a C++
+// functor, so the semirings are enumerated (include/mi355_spmv.h).  min/max never round, so
+// MIN_PLUS and MAX_TIMES results are bit-exact whatever the reduction order.
+template <int S, typename val_t> struct Semiring;
+template <typename val_t> struct Semiring<MI355_SEMIRING_PLUS_TIMES, val_t> {
+    __device__ static __forceinline__ val_t identity() { return val_t(0); }
+    __device__ static __forceinline__ val_t combine(val_t a, val_t x) { return a * x; }
+    __device__ static __forceinline__ val_t reduce(val_t u, val_t v) { return u + v; }
+};
+template <typename val_t> struct Semiring<MI355_SEMIRING_MIN_PLUS, val_t> {
+    __device__ static __forceinline__ val_t identity() { return val_t(INFINITY); }
+    __device__ static __forceinline__ val_t combine(val_t a, val_t x) { return a + x; }
+    __device__ static __forceinline__ val_t reduce(val_t u, val_t v) { return v < u ? v : u; }
+};
+template <typename val_t> struct Semiring<MI355_SEMIRING_MAX_TIMES, val_t> {
+    __device__ static __forceinline__ val_t identity() { return val_t(-INFINITY); }
+    __device__ static __forceinline__ val_t combine(val_t a, val_t x) { return a * x; }
+    __device__ static __forceinline__ val_t reduce(val_t u, val_t v) { return u < v ? v : u; }
+};
 
 // ---- K6: tile start coordinates ------------------------------------------------
 template <typename off_t>
@@ -78,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void merge_search_kernel(
 }
 
 // ---- K7: one run of consecutive tiles per workgroup ---------------------------------
-template <int IPT, bool VEC, bool WINDOW, typename off_t, typename val_t>
+template <int IPT, bool VEC, bool WINDOW, int S, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     int32_t n_rows, int32_t n_cols, int64_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
@@ -137,7 +161,8 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     };
     int64_t re_next = fetch_row_end(x0, x1);
 
-    val_t block_carry = val_t(0);   // sum so far of the row left open by the previous tile of this run
+    using SR = Semiring<S, val_t>;  // S = 0: the ordinary (+, *) of every other kind
+    val_t block_carry = SR::identity();   // sum so far of the row left open by the previous tile of this run
     for (int64_t t = first; t < last; ++t) {
         int x2 = x1;
         int64_t y2 = y1;
@@ -162,14 +187,14 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
                     for (int e = 0; e < 4; ++e) {
                         const unsigned rel = unsigned(c[g][e] - win.lo);
                         const bool in = rel < unsigned(win.len);
-                        p[e] = a[g][e] * win.s_x[in ? rel : 0u];
+                        p[e] = SR::combine(a[g][e], win.s_x[in ? rel : 0u]);
                         need[e] = !in && (rel0 + e >= 0) && (rel0 + e < tn);
                         any_need |= need[e];
                     }
                     if (any_need) {                      // rare: loaded and consumed inside the branch
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            if (need[e]) p[e] = a[g][e] * x[c[g][e]];
+                            if (need[e]) p[e] = SR::combine(a[g][e], x[c[g][e]]);
                         }
                     }
                     *reinterpret_cast<v4*>(&s_nz[4 * (tid + g * kBlock)]) = p;
@@ -184,13 +209,13 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
                 for (int g = 0; g < G; ++g) {
                     v4 p;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) p[e] = a[g][e] * xv[g][e];
+                    for (int e = 0; e < 4; ++e) p[e] = SR::combine(a[g][e], xv[g][e]);
                     *reinterpret_cast<v4*>(&s_nz[4 * (tid + g * kBlock)]) = p;
                 }
             }
             if (y1 > nnz_vec) {   // uniform, at most one tile: the nonzeros past the last whole group
                 const int64_t k = (y0 > nnz_vec ? y0 : nnz_vec) + tid;
-                if (k < y1) s_nz[int(k - y0) + shift] = Ax[k] * x[Aj[k]];
+                if (k < y1) s_nz[int(k - y0) + shift] = SR::combine(Ax[k], x[Aj[k]]);
             }
             // the next tile's stream goes in flight now and lands while this tile is walked
             if (t + 1 < last) issue(y1);
@@ -198,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
             // Aj / Ax not 16-byte aligned (an offset view): 4-byte-per-lane form
             for (int i = tid; i < tn; i += kBlock) {
                 const int32_t col = Aj[y0 + i];
-                s_nz[i] = Ax[y0 + i] * window_gather<val_t>(win, x, col, true);
+                s_nz[i] = SR::combine(Ax[y0 + i], window_gather<val_t>(win, x, col, true));
             }
         }
         // (2) row ends, relative to y0; the row still open at the tile end never ends here
@@ -222,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
         int cx = lo, cy = d0 - lo;
 
         // (4) walk: a nonzero extends the running row sum, a row end closes it
-        val_t run = val_t(0), first_val = val_t(0);
+        val_t run = SR::identity(), first_val = SR::identity();
         int first_end = -1;
         int re = s_re[cx];
         const int cnt = d1 - d0;
@@ -230,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
         for (int k = 0; k < IPT; ++k) {
             if (k < cnt) {
                 if (cy < re) {
-                    run += s_nz[cy + shift];
+                    run = SR::reduce(run, s_nz[cy + shift]);
                     ++cy;
                 } else {
                     if (first_end < 0) {
@@ -239,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
                     } else {
                         y[int64_t(x0) + cx] = run;        // opened and closed inside this thread
                     }
-                    run = val_t(0);
+                    run = SR::identity();
                     ++cx;
                     re = s_re[cx];
                 }
@@ -256,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
             const val_t ov = __shfl_up(sv, d, kWave);
             const int of = __shfl_up(sf, d, kWave);
             if (lane64 >= d) {
-                if (!sf) sv = ov + sv;
+                if (!sf) sv = SR::reduce(ov, sv);
                 sf |= of;
             }
         }
@@ -266,11 +291,11 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
         }
         __syncthreads();
         val_t prefix = block_carry;  // block-inclusive value at the end of the previous wave
-        for (int w = 0; w < wave; ++w) prefix = s_wave_flag[w] ? s_wave_sum[w] : prefix + s_wave_sum[w];
-        const val_t incl = sf ? sv : prefix + sv;
+        for (int w = 0; w < wave; ++w) prefix = s_wave_flag[w] ? s_wave_sum[w] : SR::reduce(prefix, s_wave_sum[w]);
+        const val_t incl = sf ? sv : SR::reduce(prefix, sv);
         val_t carry_in = __shfl_up(incl, 1, kWave);
         if (lane64 == 0) carry_in = prefix;
-        if (first_end >= 0) y[int64_t(x0) + first_end] = carry_in + first_val;
+        if (first_end >= 0) y[int64_t(x0) + first_end] = SR::reduce(carry_in, first_val);
         if (tid == kBlock - 1) s_carry = incl;   // the row still open at the end of the tile
         __syncthreads();                          // also frees s_nz / s_re / s_wave_* for the next tile
         block_carry = s_carry;
@@ -285,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
 }
 
 // ---- K8: add the carries of rows that straddle runs ------------------------------------
-template <typename val_t>
+template <int S, typename val_t>
 __global__ __launch_bounds__(kBlock) void merge_fixup_kernel(
     int64_t n_carries, int32_t n_rows, const int32_t* __restrict__ carry_row,
     const val_t* __restrict__ carry_val, val_t* __restrict__ y) {
@@ -295,8 +320,9 @@ __global__ __launch_bounds__(kBlock) void merge_fixup_kernel(
     if (r >= n_rows) return;
     if (t > 0 && carry_row[t - 1] == r) return;  // not the first run carrying row r
     val_t s = carry_val[t];
-    for (int64_t u = t + 1; u < n_carries && carry_row[u] == r; ++u) s += carry_val[u];
-    y[r] += s;
+    using SR = Semiring<S, val_t>;
+    for (int64_t u = t + 1; u < n_carries && carry_row[u] == r; ++u) s = SR::reduce(s, carry_val[u]);
+    y[r] = SR::reduce(y[r], s);
 }
 
 // ---- host side -----------------------------------------------------------------------
@@ -306,9 +332,8 @@ static int env_int(const char* name, int dflt) {
 }
 
 void shape_merge(Plan& p) {
-    // tuning knobs (defaults are the measured best): MI355_MERGE_IPT = 8|16 items per
-    // thread, MI355_MERGE_TPS = tiles per run (and MI355_SPMV_WINDOW = 0|1, analyze.hip)
-    const int ipt = env_int("MI355_MERGE_IPT", 8) == 16 ? 16 : 8;
+    // tuning knobs: MI355_MERGE_TPS = tiles per run (and MI355_SPMV_WINDOW = 0|1, analyze.hip)
+    const int ipt = 8;   // (16 measured no better; one instantiation per semiring instead)
     p.lanes_per_row = 0;
     p.elems_per_lane = ipt;            // reported as items per thread for this kind
     p.tile_items = int64_t(kBlock) * ipt - 4;
@@ -353,28 +378,34 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
     const size_t dyn = size_t(cap) * sizeof(val_t);
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
     const dim3 grid((unsigned)p.n_super), block(kBlock);
-#define MI355_MERGE_LAUNCH(IPT_, VEC_, WIN_)                                                                  \
-    hipLaunchKernelGGL((merge_tile_kernel<IPT_, VEC_, WIN_, off_t, val_t>), grid, block, dyn, s, p.n_rows,     \
+#define MI355_MERGE_LAUNCH(VEC_, WIN_, S_)                                                                    \
+    hipLaunchKernelGGL((merge_tile_kernel<8, VEC_, WIN_, S_, off_t, val_t>), grid, block, dyn, s, p.n_rows,    \
                        p.n_cols, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz, p.carry_row,              \
                        static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super, cap, hint)
+#define MI355_MERGE_SEMIRING(S_)                                                    \
+    do {                                                                            \
+        if (!vec) MI355_MERGE_LAUNCH(false, false, S_);                             \
+        else if (cap > 0) MI355_MERGE_LAUNCH(true, true, S_);                       \
+        else MI355_MERGE_LAUNCH(true, false, S_);                                   \
+        MI355_HIP_TRY(hipGetLastError());                                           \
+        if (p.n_super > 1) {                                                        \
+            const unsigned g = unsigned((p.n_super + kBlock - 1) / kBlock);         \
+            hipLaunchKernelGGL((merge_fixup_kernel<S_, val_t>), dim3(g), dim3(kBlock), 0, s, p.n_super, p.n_rows, \
+                               p.carry_row, static_cast<const val_t*>(p.carry_val), y);                      \
+            MI355_HIP_TRY(hipGetLastError());                                       \
+        }                                                                           \
+    } while (0)
     const bool vec = aligned && p.nnz >= 4;
-    if (p.elems_per_lane == 16) {
-        if (!vec) MI355_MERGE_LAUNCH(16, false, false);
-        else if (cap > 0) MI355_MERGE_LAUNCH(16, true, true);
-        else MI355_MERGE_LAUNCH(16, true, false);
-    } else {
-        if (!vec) MI355_MERGE_LAUNCH(8, false, false);
-        else if (cap > 0) MI355_MERGE_LAUNCH(8, true, true);
-        else MI355_MERGE_LAUNCH(8, true, false);
+    switch (p.semiring) {
+        case MI355_SEMIRING_PLUS_TIMES: MI355_MERGE_SEMIRING(MI355_SEMIRING_PLUS_TIMES); break;
+        case MI355_SEMIRING_MIN_PLUS:   MI355_MERGE_SEMIRING(MI355_SEMIRING_MIN_PLUS); break;
+        case MI355_SEMIRING_MAX_TIMES:  MI355_MERGE_SEMIRING(MI355_SEMIRING_MAX_TIMES); break;
+        default:
+            set_error("merge: unknown semiring %d", p.semiring);
+            return MI355_SPMV_EINVAL;
     }
+#undef MI355_MERGE_SEMIRING
 #undef MI355_MERGE_LAUNCH
-    MI355_HIP_TRY(hipGetLastError());
-    if (p.n_super > 1) {
-        const unsigned g = unsigned((p.n_super + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL((merge_fixup_kernel<val_t>), dim3(g), dim3(kBlock), 0, s, p.n_super, p.n_rows,
-                           p.carry_row, static_cast<const val_t*>(p.carry_val), y);
-        MI355_HIP_TRY(hipGetLastError());
-    }
     return MI355_SPMV_OK;
 }
 

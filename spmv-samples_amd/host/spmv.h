@@ -21,10 +21,11 @@
 #include "spmv/mi355.hpp"
 
 /// SPMV kind strings and its function
-#define SPMV_KINDS                    \
-    X("hip_vector", SpMV_hip_vector)  \
-    X("hip_merge", SpMV_hip_merge)    \
-    X("hip_light", SpMV_hip_light)
+#define SPMV_KINDS                                    \
+    X("hip_vector", SpMV_hip_vector)                  \
+    X("hip_merge", SpMV_hip_merge)                    \
+    X("hip_light", SpMV_hip_light)                    \
+    X("hip_merge_genl", SpMV_hip_merge_generalized)
 
 template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,
           typename vec_y_value_t>

@@ -38,10 +38,18 @@ inline void check(int status, const char* what, const char* file, int line) {
 }
 #define MI355_CHECK(expr) ::mi355_host::check((expr), #expr, __FILE__, __LINE__)
 
+// Semiring tags for the generalized merge kind.  The reference passes a functor_t with static
+// initialize / combine / reduce (include/spmv/merge_genl/merge_genl.cuh:19-38) into device code; the
+// kernels here live behind a C ABI, so the functor is a tag naming one of the built-in semirings.
+struct PlusTimes { static constexpr int id = MI355_SEMIRING_PLUS_TIMES; };   // the reference's MergeFunctor
+struct MinPlus   { static constexpr int id = MI355_SEMIRING_MIN_PLUS; };
+struct MaxTimes  { static constexpr int id = MI355_SEMIRING_MAX_TIMES; };
+
 template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,
           typename vec_y_value_t>
 void run_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap, const index_t* Aj,
-              const mat_value_t* Ax, const vec_x_value_t* x, vec_y_value_t* y) {
+              const mat_value_t* Ax, const vec_x_value_t* x, vec_y_value_t* y,
+              int semiring = MI355_SEMIRING_PLUS_TIMES) {
     static_assert(std::is_same<index_t, int>::value || std::is_same<index_t, int32_t>::value,
                   "mi355 kinds: index_t must be a 32-bit int (reference main.cu:15)");
     static_assert(sizeof(offset_t) == 4 || sizeof(offset_t) == 8, "mi355 kinds: offset_t must be 32- or 64-bit");
@@ -57,6 +65,7 @@ void run_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const offs
     mi355_spmv_plan* plan = nullptr;
     MI355_CHECK(mi355_spmv_plan_create(&plan, kind, off_type, val_type, (int32_t)n_rows, (int32_t)n_cols,
                                        (int64_t)nnz, Ap, reinterpret_cast<const int32_t*>(Aj), MI355_PLAN_DEFAULT));
+    if (semiring != MI355_SEMIRING_PLUS_TIMES) MI355_CHECK(mi355_spmv_plan_set_semiring(plan, semiring));
     Timer::kernel_start();
     MI355_CHECK(mi355_spmv_plan_execute(plan, Ax, x, y, /*stream=*/nullptr));
     MI355_CHECK(mi355_spmv_stream_synchronize(/*stream=*/nullptr));
@@ -80,3 +89,13 @@ MI355_DEFINE_KIND(SpMV_hip_vector, MI355_KIND_VECTOR)
 MI355_DEFINE_KIND(SpMV_hip_merge, MI355_KIND_MERGE)
 /// LightSpMV-style dynamic row distribution (sharded atomic row counters)
 MI355_DEFINE_KIND(SpMV_hip_light, MI355_KIND_LIGHT)
+
+/// generalized merge-path SpMV (cf. SpMV_merge_based_generalized, merge_genl.cuh:41-79);
+/// functor_t is one of mi355_host::PlusTimes (default, the reference's MergeFunctor), MinPlus, MaxTimes
+template <typename functor_t = ::mi355_host::PlusTimes, typename index_t, typename offset_t,
+          typename mat_value_t, typename vec_x_value_t, typename vec_y_value_t>
+void SpMV_hip_merge_generalized(index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap,
+                                const index_t* Aj, const mat_value_t* Ax, const vec_x_value_t* x,
+                                vec_y_value_t* y) {
+    ::mi355_host::run_kind(MI355_KIND_MERGE, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, functor_t::id);
+}

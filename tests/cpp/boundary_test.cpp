@@ -95,7 +95,7 @@ static int run_combo(const char* combo, int n_rows, int n_cols, int max_len) {
             if (!(err <= bound)) ++bad;                                                                 \
             if (err > worst) worst = err;                                                               \
         }                                                                                               \
-        std::printf("[%-10s] %-8s rows=%d nnz=%lld max_err=%.3e bad_rows=%d total=%lldus kernel=%lldus\n", \
+        std::printf("[%-14s] %-8s rows=%d nnz=%lld max_err=%.3e bad_rows=%d total=%lldus kernel=%lldus\n", \
                     label, combo, n_rows, (long long)nnz, worst, bad, (long long)Timer::total_cost(),   \
                     (long long)Timer::kernel_cost());                                                   \
         failures += bad ? 1 : 0;                                                                        \

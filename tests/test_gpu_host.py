@@ -29,8 +29,8 @@ def test_cpp_boundary_all_labels_and_types():
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ALL PASSED" in r.stdout
-    for label in ("hip_vector", "hip_merge", "hip_light"):
-        assert r.stdout.count("[%-10s]" % label) == 4
+    for label in ("hip_vector", "hip_merge", "hip_light", "hip_merge_genl"):
+        assert r.stdout.count("[%-14s]" % label) == 4
 
 
 def test_cpp_boundary_unknown_label_exits_like_the_reference():

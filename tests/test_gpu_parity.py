@@ -319,3 +319,50 @@ def test_more_than_2_to_31_nonzeros_with_64bit_offsets(sp, kind):
     xe = (torch.arange(n_cols, device=DEV) % 2 == 0).to(torch.float32)
     sp.spmv(kind, n_rows, n_cols, nnz, Ap, Aj, Ax, xe, y)
     assert torch.equal(y, torch.full((n_rows,), float(per_row // 2), device=DEV))
+
+
+# ---- generalized merge-path SpMV ---------------------------------------------
+
+@pytest.mark.parametrize("semiring", ["plus_times", "min_plus", "max_times"])
+@pytest.mark.parametrize("off,val", COMBOS)
+def test_generalized_merge_semirings(sp, oracle, semiring, off, val):
+    """min and max never round and a+x / a*x round once, so (min,+) and (max,*) must equal the
+    reference's generalized CPU loop bit for bit whatever the reduction order; (+,*) within the bound.
+    Empty rows yield the semiring's identity; one row spans many tiles."""
+    rng = np.random.RandomState(77)
+    Ap, Aj, Ax = random_csr(rng, 30011, 2000, 25, NP[off], NP[val], long_row=70000)
+    x = (rng.rand(2000) * 2 - 1).astype(NP[val])
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    y = torch.full((30011,), float("nan"), dtype=d(Ax).dtype, device=DEV)
+    sp.spmv_genl(semiring, 30011, 2000, int(Ap[-1]), d(Ap), d(Aj), d(Ax), d(x), y)
+    got = y.cpu().numpy()
+    want = oracle.spmv_genl_serial(sp.capi.SEMIRINGS[semiring], Ap, Aj, Ax, x)
+    assert not np.any(np.isnan(got))
+    if semiring == "plus_times":
+        assert_parity(oracle, Ap, Aj, Ax, x, got)
+    else:
+        assert np.array_equal(got, want)
+
+
+def test_semiring_is_a_merge_feature_and_plans_keep_it(sp, oracle):
+    rng = np.random.RandomState(78)
+    Ap, Aj, Ax = random_csr(rng, 5000, 300, 12)
+    x = (rng.rand(300) * 2 - 1).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    dAp, dAj, dAx, dx = d(Ap), d(Aj), d(Ax), d(x)
+    p = sp.Plan("vector", 5000, 300, int(Ap[-1]), dAp, dAj, torch.float32)
+    with pytest.raises(RuntimeError, match="not supported"):
+        p.set_semiring("min_plus")                           # only the merge kind is generalized, as in the reference
+    p.destroy()
+    p = sp.Plan("merge", 5000, 300, int(Ap[-1]), dAp, dAj, torch.float32)
+    p.set_semiring("min_plus")
+    y = torch.empty(5000, device=DEV)
+    for _ in range(2):
+        p.execute(dAx, dx, y)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), oracle.spmv_genl_serial(1, Ap, Aj, Ax, x))
+    p.set_semiring("plus_times")
+    p.execute(dAx, dx, y)
+    torch.cuda.synchronize()
+    assert_parity(oracle, Ap, Aj, Ax, x, y.cpu().numpy())
+    p.destroy()

@@ -177,3 +177,24 @@ def test_merge_tile_coords_properties(oracle):
         assert Ap[xs[t]] <= ys[t]
         if xs[t] < n:
             assert ys[t] <= Ap[xs[t] + 1]
+
+
+# ---- generalized (semiring) SpMV: cpu_navie.hpp:20-34 -------------------------------------------
+
+@pytest.mark.parametrize("semiring", [0, 1, 2])
+@pytest.mark.parametrize("off,val", COMBOS)
+def test_generalized_serial_matches_reference_build(oracle, ref, semiring, off, val):
+    """The reference's own SpMV_genl_cpu_navie<functor_t>, instantiated in oracle/ref_driver.cpp with
+    (+,*), (min,+) and (max,*), against the restatement — bit for bit, empty rows included."""
+    rng = np.random.RandomState(40 + semiring)
+    Ap, Aj, Ax = random_csr(rng, 500, 200, 30, NP[off], NP[val], long_row=900)
+    x = (rng.rand(200) * 2 - 1).astype(NP[val])
+    want = ref.spmv_genl_cpu(semiring, 200, Ap, Aj, Ax, x)
+    got = oracle.spmv_genl_serial(semiring, Ap, Aj, Ax, x)
+    assert np.array_equal(got, want)
+    empty = np.diff(Ap.astype(np.int64)) == 0
+    assert empty.any()
+    ident = {0: 0.0, 1: np.inf, 2: -np.inf}[semiring]
+    assert np.all(got[empty] == ident)                       # an empty row yields initialize()
+    if semiring == 0:
+        assert np.array_equal(got, oracle.spmv_serial(Ap, Aj, Ax, x))
