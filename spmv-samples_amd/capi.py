@@ -13,7 +13,7 @@ import os
 import torch  # imported before the library so both share one HIP runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmi355spmv.so")
+LIB_PATH = os.environ.get("MI355_SPMV_LIB") or os.path.join(_HERE, "lib", "libmi355spmv.so")
 
 KINDS = {"vector": 0, "merge": 1, "light": 2}
 # labels the C++ host header registers in SPMV_KINDS (host/spmv.h)
