@@ -1,24 +1,26 @@
 // spmv.h — the operator boundary, MI355X build.
 //
-// Same contract as the reference's include/spmv.h:18-48: one SPMV_KINDS X-macro of
-// (label, function) rows, and SpMV<index_t, offset_t, mat_value_t, vec_x_value_t,
-// vec_y_value_t>(kind_str, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y) that expands the
-// macro into a label-compare chain, brackets the call with Timer::total_start/stop
-// and exits with the reference's message on an unknown label (spmv.h:46-47).
+// Contract of the reference's include/spmv.h:18-48, kept: one SPMV_KINDS X-macro of
+// (label, function) rows; SpMV<index_t, offset_t, mat_value_t, vec_x_value_t, vec_y_value_t>(
+// kind_str, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y) finds the row whose label equals kind_str
+// (first match in macro order), brackets the call with Timer::total_start/stop, and on an
+// unknown label prints the reference's message and exits with EXIT_FAILURE (spmv.h:46-47).
+// How the macro is expanded differs (a table of captureless lambdas instead of an if-chain);
+// what a caller or a new kind sees does not: a kind is still a function template
+// `SpMV_<name>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y)` plus one X row (README.md:28-45).
 //
-// In the reference tree the MI355X kinds register ALONGSIDE the CUDA kinds by
-// adding `#include "spmv/mi355.hpp"` and the three X rows below to its SPMV_KINDS
-// (INTEGRATION.md).  This stand-alone copy of the boundary lists only the kinds
-// that exist on an MI355X box; the CUDA/cuSPARSE/CUB kinds of the reference
-// (spmv.h:19-27) have no place on this hardware.
+// In the reference tree the MI355X kinds register ALONGSIDE the CUDA kinds by adding
+// `#include "spmv/mi355.hpp"` and the X rows below to its SPMV_KINDS.  This
+// stand-alone copy lists only the kinds that exist on an MI355X box; the CUDA / cuSPARSE / CUB
+// kinds of the reference (spmv.h:19-27) have no place on this hardware.
 #pragma once
 
 #include <cstdlib>
 #include <iostream>
 #include <string>
 
-#include "timer.hpp"
 #include "spmv/mi355.hpp"
+#include "timer.hpp"
 
 /// SPMV kind strings and its function
 #define SPMV_KINDS                                    \
@@ -31,16 +33,26 @@ template <typename index_t, typename offset_t, typename mat_value_t, typename ve
           typename vec_y_value_t>
 void SpMV(const std::string& kind_str, index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap,
           const index_t* Aj, const mat_value_t* Ax, const vec_x_value_t* x, vec_y_value_t* y) {
-#define X(label, func)                               \
-    if (kind_str == label) {                         \
-        Timer::total_start();                        \
-        func(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y); \
-        Timer::total_stop();                         \
-        return;                                      \
-    }
-    SPMV_KINDS
+    using kind_fn = void (*)(index_t, index_t, offset_t, const offset_t*, const index_t*, const mat_value_t*,
+                             const vec_x_value_t*, vec_y_value_t*);
+    struct kind_row {
+        const char* label;
+        kind_fn call;
+    };
+    static const kind_row rows[] = {
+#define X(label, func)                                                                                   \
+    {label, [](index_t r, index_t c, offset_t z, const offset_t* p, const index_t* j, const mat_value_t* a, \
+               const vec_x_value_t* xv, vec_y_value_t* yv) { func(r, c, z, p, j, a, xv, yv); }},
+        SPMV_KINDS
 #undef X
-
+    };
+    for (const kind_row& row : rows) {
+        if (kind_str != row.label) continue;
+        Timer::total_start();
+        row.call(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);
+        Timer::total_stop();
+        return;
+    }
     std::cerr << "SpMV kind \"" << kind_str << "\" is NOT SUPPROT\n";
     std::exit(EXIT_FAILURE);
 }
