@@ -128,6 +128,11 @@ int mi355_spmv_plan_create(mi355_spmv_plan** plan, int kind, int off_type, int v
 int mi355_spmv_plan_execute(mi355_spmv_plan* plan, const void* Ax, const void* x, void* y,
                             void* stream);
 int mi355_spmv_plan_destroy(mi355_spmv_plan* plan);
+/* y = alpha * A x + beta * y for the following executes (any kind, (+, *) semiring; default 1, 0:
+ * y overwritten).  SURVEY §8(f)-4: the reference's cuSPARSE kind passes alpha = 1, beta = 0
+ * (include/spmv/cusparse.cuh:42-43) and its vendored CUB carries the same two scalars, disabled
+ * (merge_based/agent_spmv_orig.cuh:425-433, dispatch_spmv_orig.cuh:802).  y is read only when beta != 0. */
+int mi355_spmv_plan_set_alpha_beta(mi355_spmv_plan* plan, double alpha, double beta);
 /* MERGE plans only (ENOTSUP otherwise): choose the semiring of the following executes.  */
 int mi355_spmv_plan_set_semiring(mi355_spmv_plan* plan, int semiring);
 /* Block the host until `stream` has drained (hipStreamSynchronize), so that a

@@ -26,7 +26,7 @@ SEMIRINGS = {"plus_times": 0, "min_plus": 1, "max_times": 2}
 EXPORTS = (
     ["mi355_spmv_%s_%s_%s" % (k, o, v) for k in KINDS for o in ("i32", "i64") for v in ("f32", "f64")]
     + ["mi355_spmv_merge_genl_%s_%s" % (o, v) for o in ("i32", "i64") for v in ("f32", "f64")]
-    + ["mi355_spmv_plan_set_semiring"]
+    + ["mi355_spmv_plan_set_semiring", "mi355_spmv_plan_set_alpha_beta"]
     + ["mi355_spmv_plan_create", "mi355_spmv_plan_execute", "mi355_spmv_plan_destroy",
        "mi355_spmv_plan_get_info", "mi355_spmv_stream_synchronize", "mi355_spmv_plan_merge_coords", "mi355_spmv_version",
        "mi355_spmv_status_string", "mi355_spmv_last_error", "mi355_spmv_device_count"]
@@ -65,6 +65,7 @@ def lib():
         L.mi355_spmv_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi355_spmv_plan_destroy.argtypes = [C.c_void_p]
         L.mi355_spmv_plan_set_semiring.argtypes = [C.c_void_p, C.c_int]
+        L.mi355_spmv_plan_set_alpha_beta.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.mi355_spmv_plan_get_info.argtypes = [C.c_void_p, C.POINTER(PlanInfo)]
         L.mi355_spmv_plan_merge_coords.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -164,6 +165,11 @@ class Plan:
     def set_semiring(self, semiring):
         sr = SEMIRINGS[semiring] if isinstance(semiring, str) else int(semiring)
         _check(lib().mi355_spmv_plan_set_semiring(self._h, C.c_int(sr)), "mi355_spmv_plan_set_semiring")
+
+    def set_alpha_beta(self, alpha, beta):
+        """y = alpha * A x + beta * y for the following executes (default 1, 0)."""
+        _check(lib().mi355_spmv_plan_set_alpha_beta(self._h, C.c_double(alpha), C.c_double(beta)),
+               "mi355_spmv_plan_set_alpha_beta")
 
     def info(self):
         pi = PlanInfo()

@@ -145,6 +145,8 @@ int mi355_spmv_plan_create(mi355_spmv_plan** out, int kind, int off_type, int va
     p.kind = kind; p.off_type = off_type; p.val_type = val_type; p.flags = flags;
     p.n_rows = n_rows; p.n_cols = n_cols; p.nnz = nnz; p.Ap = Ap; p.Aj = Aj;
     p.elems_per_lane = 4;
+    p.alpha = 1.0;
+    p.beta = 0.0;
     {
         const int st = probe_structure(p);   // one tiny kernel + one 16-byte copy (synchronises)
         if (st != MI355_SPMV_OK) { delete h; return st; }
@@ -194,7 +196,23 @@ int mi355_spmv_plan_set_semiring(mi355_spmv_plan* h, int semiring) {
         set_error("plan_set_semiring: only the merge kind is generalized (as in the reference)");
         return MI355_SPMV_ENOTSUP;
     }
+    if (semiring != MI355_SEMIRING_PLUS_TIMES && (h->p.alpha != 1.0 || h->p.beta != 0.0)) {
+        set_error("plan_set_semiring: alpha/beta are set; they are defined for (+, *) only");
+        return MI355_SPMV_ENOTSUP;
+    }
     h->p.semiring = semiring;
+    return MI355_SPMV_OK;
+}
+
+int mi355_spmv_plan_set_alpha_beta(mi355_spmv_plan* h, double alpha, double beta) {
+    g_err[0] = 0;
+    if (!h) { set_error("plan_set_alpha_beta: null plan"); return MI355_SPMV_EINVAL; }
+    if (h->p.semiring != MI355_SEMIRING_PLUS_TIMES && (alpha != 1.0 || beta != 0.0)) {
+        set_error("plan_set_alpha_beta: scaling is defined for the (+, *) semiring only");
+        return MI355_SPMV_ENOTSUP;
+    }
+    h->p.alpha = alpha;
+    h->p.beta = beta;
     return MI355_SPMV_OK;
 }
 

@@ -55,6 +55,7 @@ struct Plan {
     int64_t tiles_per_super, n_super;   // consecutive tiles one workgroup walks; number of such groups
     bool coords_valid;
     int semiring;               // MERGE: MI355_SEMIRING_* (0 = plus-times)
+    double alpha, beta;         // y = alpha * A x + beta * y (1, 0 by default)
     // structure probe (plan creation): band of (column - row) seen on sampled rows
     int64_t band_lo, band_hi;   // valid when probe_ok
     bool probe_ok;

@@ -24,11 +24,13 @@ template <int T, int R, int NSEG, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void csr_vector_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, int32_t rows_per_chunk,
-    int32_t window_cap, BandHint hint, SegmentPlan segs) {
+    int32_t window_cap, BandHint hint, SegmentPlan segs, val_t alpha, val_t beta) {
     // NSEG: 0 = no window (plain gathers), 1 = one window of x in LDS, kMaxSegments = several bands
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2 * (kBlock / kWave)];
-    const ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, rows_per_chunk);
+    ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, rows_per_chunk);
+    scr.alpha = alpha;
+    scr.beta = beta;
     const unsigned chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int64_t rb = int64_t(chunk) * rows_per_chunk;
     const int64_t re = min(rb + rows_per_chunk, int64_t(n_rows));
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_window_kernel(
 template <int T, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     int32_t n_rows, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
-    const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y) {
+    const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, val_t alpha, val_t beta) {
     constexpr int ROWS_PER_BLOCK = kBlock / T;
     const unsigned blk = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x & (T - 1);
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     }
     val_t sum = row_partial<T, off_t, val_t>(start, end, lane, Aj, Ax, x);
     sum = vector_reduce<T, val_t>(sum);
-    if (live && lane == 0) y[row] = sum;
+    if (live && lane == 0) y[row] = (beta != val_t(0)) ? alpha * sum + beta * y[row] : alpha * sum;
 }
 
 template <typename val_t> constexpr int rows_in_flight() { return sizeof(val_t) == 4 ? 4 : 2; }
@@ -97,7 +99,7 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
     SegmentPlan segs;
     segs.n = p.n_seg;
     for (int i = 0; i < kMaxSegments; ++i) { segs.lo[i] = p.seg_lo[i]; segs.hi[i] = p.seg_hi[i]; }
-#define MI355_VEC_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, (int32_t)p.rows_per_chunk, (int32_t)p.window_elems, hint, segs
+#define MI355_VEC_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, (int32_t)p.rows_per_chunk, (int32_t)p.window_elems, hint, segs, (val_t)p.alpha, (val_t)p.beta
 #define MI355_VEC_CASE(TT)                                                                                   \
     case TT:                                                                                                 \
         if (p.window_elems > 0 && p.n_seg >= 2)                                                              \
@@ -133,7 +135,7 @@ static int launch_vector_plain(const Plan& p, const off_t* Ap, const val_t* Ax, 
 #define MI355_VEC_CASE(TT)                                                                                \
     case TT:                                                                                              \
         hipLaunchKernelGGL((csr_vector_kernel<TT, off_t, val_t>), grid, block, 0, s, p.n_rows, nnz, Ap, p.Aj, \
-                           Ax, x, y);                                                                     \
+                           Ax, x, y, (val_t)p.alpha, (val_t)p.beta);                                      \
         break;
     switch (p.lanes_per_row) {
         MI355_VEC_CASE(2)

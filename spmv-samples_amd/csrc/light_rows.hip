@@ -51,11 +51,13 @@ __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
     unsigned long long* __restrict__ counters, int32_t rows_per_chunk, int32_t window_cap, BandHint hint,
-    SegmentPlan segs) {
+    SegmentPlan segs, val_t alpha, val_t beta) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2 * (kBlock / kWave)];
     __shared__ unsigned long long s_got;
-    const ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, rows_per_chunk);
+    ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, rows_per_chunk);
+    scr.alpha = alpha;
+    scr.beta = beta;
     const int home = blockIdx.x % kXcds;
     for (int visit = 0; visit < kXcds; ++visit) {
         const int shard = (home + visit) % kXcds;
@@ -91,7 +93,7 @@ template <int T, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void light_rows_kernel(
     int32_t n_rows, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
-    unsigned long long* __restrict__ counters, int32_t rows_per_chunk) {
+    unsigned long long* __restrict__ counters, int32_t rows_per_chunk, val_t alpha, val_t beta) {
     constexpr int ROWS_PER_STEP = kWave / T;
     const int lane64 = threadIdx.x & (kWave - 1);
     const int lane = threadIdx.x & (T - 1);
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void light_rows_kernel(
                 }
                 val_t sum = row_partial<T, off_t, val_t>(start, end, lane, Aj, Ax, x);
                 sum = vector_reduce<T, val_t>(sum);
-                if (live && lane == 0) y[row] = sum;
+                if (live && lane == 0) y[row] = (beta != val_t(0)) ? alpha * sum + beta * y[row] : alpha * sum;
             }
         }
     }
@@ -173,7 +175,7 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
     SegmentPlan segs;
     segs.n = p.n_seg;
     for (int i = 0; i < kMaxSegments; ++i) { segs.lo[i] = p.seg_lo[i]; segs.hi[i] = p.seg_hi[i]; }
-#define MI355_LIGHT_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, p.counters, chunk, (int32_t)p.window_elems, hint, segs
+#define MI355_LIGHT_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, p.counters, chunk, (int32_t)p.window_elems, hint, segs, (val_t)p.alpha, (val_t)p.beta
 #define MI355_LIGHT_CASE(TT)                                                                                   \
     case TT:                                                                                                   \
         if (p.window_elems > 0 && p.n_seg >= 2)                                                                \
@@ -208,7 +210,7 @@ static int launch_light_plain(const Plan& p, const off_t* Ap, const val_t* Ax, c
 #define MI355_LIGHT_CASE(TT)                                                                          \
     case TT:                                                                                          \
         hipLaunchKernelGGL((light_rows_kernel<TT, off_t, val_t>), grid, block, 0, s, p.n_rows, nnz, Ap, \
-                           p.Aj, Ax, x, y, p.counters, chunk);                                        \
+                           p.Aj, Ax, x, y, p.counters, chunk, (val_t)p.alpha, (val_t)p.beta);         \
         break;
     switch (p.lanes_per_row) {
         MI355_LIGHT_CASE(2)

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
     const int32_t* __restrict__ tile_row, const int64_t* __restrict__ tile_nnz,
     int32_t* __restrict__ carry_row, val_t* __restrict__ carry_val, int64_t n_tiles, int32_t tiles_per_super,
-    int32_t window_cap, BandHint hint) {
+    int32_t window_cap, BandHint hint, val_t alpha, val_t beta) {
     constexpr int G = IPT / 4;
     using v4 = typename Vec4<val_t>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window_cap values of x
@@ -162,6 +162,14 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     int64_t re_next = fetch_row_end(x0, x1);
 
     using SR = Semiring<S, val_t>;  // S = 0: the ordinary (+, *) of every other kind
+    // y = alpha * (A x) + beta * y for the ordinary semiring (the fix-up adds alpha * carry); 1, 0 otherwise
+    auto put = [&](int64_t row, val_t v) {
+        if constexpr (S == MI355_SEMIRING_PLUS_TIMES) {
+            v = alpha * v;
+            if (beta != val_t(0)) v += beta * y[row];
+        }
+        y[row] = v;
+    };
     val_t block_carry = SR::identity();   // sum so far of the row left open by the previous tile of this run
     for (int64_t t = first; t < last; ++t) {
         int x2 = x1;
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
                         first_end = cx;                   // may continue a row opened by earlier threads
                         first_val = run;
                     } else {
-                        y[int64_t(x0) + cx] = run;        // opened and closed inside this thread
+                        put(int64_t(x0) + cx, run);       // opened and closed inside this thread
                     }
                     run = SR::identity();
                     ++cx;
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
         const val_t incl = sf ? sv : SR::reduce(prefix, sv);
         val_t carry_in = __shfl_up(incl, 1, kWave);
         if (lane64 == 0) carry_in = prefix;
-        if (first_end >= 0) y[int64_t(x0) + first_end] = SR::reduce(carry_in, first_val);
+        if (first_end >= 0) put(int64_t(x0) + first_end, SR::reduce(carry_in, first_val));
         if (tid == kBlock - 1) s_carry = incl;   // the row still open at the end of the tile
         __syncthreads();                          // also frees s_nz / s_re / s_wave_* for the next tile
         block_carry = s_carry;
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
 template <int S, typename val_t>
 __global__ __launch_bounds__(kBlock) void merge_fixup_kernel(
     int64_t n_carries, int32_t n_rows, const int32_t* __restrict__ carry_row,
-    const val_t* __restrict__ carry_val, val_t* __restrict__ y) {
+    const val_t* __restrict__ carry_val, val_t* __restrict__ y, val_t alpha) {
     const int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (t >= n_carries) return;
     const int32_t r = carry_row[t];
@@ -322,6 +330,7 @@ __global__ __launch_bounds__(kBlock) void merge_fixup_kernel(
     val_t s = carry_val[t];
     using SR = Semiring<S, val_t>;
     for (int64_t u = t + 1; u < n_carries && carry_row[u] == r; ++u) s = SR::reduce(s, carry_val[u]);
+    if constexpr (S == MI355_SEMIRING_PLUS_TIMES) s = alpha * s;
     y[r] = SR::reduce(y[r], s);
 }
 
@@ -381,7 +390,7 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
 #define MI355_MERGE_LAUNCH(VEC_, WIN_, S_)                                                                    \
     hipLaunchKernelGGL((merge_tile_kernel<8, VEC_, WIN_, S_, off_t, val_t>), grid, block, dyn, s, p.n_rows,    \
                        p.n_cols, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz, p.carry_row,              \
-                       static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super, cap, hint)
+                       static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super, cap, hint, (val_t)p.alpha, (val_t)p.beta)
 #define MI355_MERGE_SEMIRING(S_)                                                    \
     do {                                                                            \
         if (!vec) MI355_MERGE_LAUNCH(false, false, S_);                             \
@@ -391,7 +400,7 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
         if (p.n_super > 1) {                                                        \
             const unsigned g = unsigned((p.n_super + kBlock - 1) / kBlock);         \
             hipLaunchKernelGGL((merge_fixup_kernel<S_, val_t>), dim3(g), dim3(kBlock), 0, s, p.n_super, p.n_rows, \
-                               p.carry_row, static_cast<const val_t*>(p.carry_val), y);                      \
+                               p.carry_row, static_cast<const val_t*>(p.carry_val), y, (val_t)p.alpha);      \
             MI355_HIP_TRY(hipGetLastError());                                       \
         }                                                                           \
     } while (0)

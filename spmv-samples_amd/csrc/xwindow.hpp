@@ -248,6 +248,7 @@ struct ChunkScratch {
     off_t* s_b;           // rows + 1 : Ap[chunk_begin .. chunk_end]
     val_t* s_y;           // rows     : results of the chunk, stored to y in one coalesced sweep
     unsigned* long_map;   // rows / 32 + 1 : one bit per row, set = long row, summed in the second pass
+    val_t alpha, beta;    // y = alpha * (A x) + beta * y   (1, 0 unless mi355_spmv_plan_set_alpha_beta)
     __device__ ChunkScratch(unsigned char* base, int window_elems, int rows) {
         s_x = reinterpret_cast<val_t*>(base);
         base += lds_align16(size_t(window_elems) * sizeof(val_t));
@@ -256,6 +257,8 @@ struct ChunkScratch {
         s_y = reinterpret_cast<val_t*>(base);
         base += lds_align16(size_t(rows) * sizeof(val_t));
         long_map = reinterpret_cast<unsigned*>(base);
+        alpha = val_t(1);
+        beta = val_t(0);
     }
 };
 
@@ -478,19 +481,28 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
         }
     }
 
-    // the chunk's results: one coalesced sweep (16-byte nontemporal stores when y is aligned)
+    // the chunk's results: one coalesced sweep (16-byte nontemporal stores when y is aligned);
+    // y = alpha * sum + beta * y_old — y is read only when beta != 0 (alpha = 1, beta = 0: plain store)
     __syncthreads();
     val_t* const yc = y + chunk_begin;
     constexpr int PER16 = 16 / int(sizeof(val_t));
-    if ((reinterpret_cast<uintptr_t>(yc) & 15u) == 0) {
+    const val_t alpha = scr.alpha, beta = scr.beta;
+    const bool scaled = (alpha != val_t(1)) || (beta != val_t(0));   // uniform
+    if (!scaled && (reinterpret_cast<uintptr_t>(yc) & 15u) == 0) {
         using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
         const int full = rows / PER16;
         for (int g = threadIdx.x; g < full; g += kBlock)
             __builtin_nontemporal_store(*reinterpret_cast<const v16*>(scr.s_y + g * PER16),
                                         reinterpret_cast<v16*>(yc + g * PER16));
         for (int i = full * PER16 + threadIdx.x; i < rows; i += kBlock) yc[i] = scr.s_y[i];
-    } else {
+    } else if (!scaled) {
         for (int i = threadIdx.x; i < rows; i += kBlock) yc[i] = scr.s_y[i];
+    } else {
+        for (int i = threadIdx.x; i < rows; i += kBlock) {
+            val_t v = alpha * scr.s_y[i];
+            if (beta != val_t(0)) v += beta * yc[i];
+            yc[i] = v;
+        }
     }
 }
 

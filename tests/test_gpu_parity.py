@@ -366,3 +366,44 @@ def test_semiring_is_a_merge_feature_and_plans_keep_it(sp, oracle):
     torch.cuda.synchronize()
     assert_parity(oracle, Ap, Aj, Ax, x, y.cpu().numpy())
     p.destroy()
+
+
+# ---- y = alpha * A x + beta * y -----------------------------------------------
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("off,val", [("i32", "f32"), ("i64", "f64")])
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (2.5, 0.0), (1.0, 1.0), (-0.75, 3.0), (0.0, 2.0)])
+def test_alpha_beta(sp, oracle, kind, off, val, alpha, beta):
+    """Bound: (len+3) eps (|alpha| sum|a x| + |beta y0|) around alpha*y64 + beta*y0 in fp64.
+    beta = 0 must ignore y's old content (NaN poison), as the reference's beta = 0 does
+    (cusparse.cuh:42-43; cpu_navie.hpp:15 overwrites)."""
+    rng = np.random.RandomState(91)
+    Ap, Aj, Ax = random_csr(rng, 9001, 700, 28, NP[off], NP[val], long_row=15000)
+    x = (rng.rand(700) * 2 - 1).astype(NP[val])
+    y0 = (rng.rand(9001) * 2 - 1).astype(NP[val]) if beta != 0.0 else np.full(9001, np.nan, NP[val])
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    dAp, dAj, dAx, dx, y = d(Ap), d(Aj), d(Ax), d(x), d(y0.copy())
+    p = sp.Plan(kind, 9001, 700, int(Ap[-1]), dAp, dAj, dAx.dtype)
+    p.set_alpha_beta(alpha, beta)
+    p.execute(dAx, dx, y)
+    torch.cuda.synchronize()
+    p.destroy()
+    got = y.cpu().numpy().astype(np.float64)
+    y64, yabs = oracle.spmv_ref64(Ap, Aj, Ax, x)
+    eps = 2.0 ** -24 if val == "f32" else 2.0 ** -53
+    y0z = np.where(np.isnan(y0), 0.0, y0).astype(np.float64)
+    want = alpha * y64 + beta * y0z
+    bound = (np.diff(Ap.astype(np.int64)) + 3) * eps * (abs(alpha) * yabs + np.abs(beta * y0z)) + 1e-300
+    assert not np.any(np.isnan(got))
+    assert np.all(np.abs(got - want) <= bound)
+
+
+def test_alpha_beta_is_for_the_ordinary_semiring_only(sp):
+    Ap = torch.tensor([0, 1], dtype=torch.int32, device=DEV)
+    Aj = torch.tensor([0], dtype=torch.int32, device=DEV)
+    p = sp.Plan("merge", 1, 1, 1, Ap, Aj, torch.float32)
+    p.set_semiring("min_plus")
+    with pytest.raises(RuntimeError, match="not supported"):
+        p.set_alpha_beta(2.0, 0.0)
+    p.set_alpha_beta(1.0, 0.0)
+    p.destroy()
