@@ -407,3 +407,53 @@ def test_alpha_beta_is_for_the_ordinary_semiring_only(sp):
         p.set_alpha_beta(2.0, 0.0)
     p.set_alpha_beta(1.0, 0.0)
     p.destroy()
+
+
+# ---- randomized structures: bands, several bands, hubs, tails ----------------------------------
+
+def _structured_csr(rng, kind_of):
+    """Small matrices built to hit the kernels' special paths: windows (one band), segments
+    (several bands), no window (scattered), long rows (hubs), empty rows, nnz not a multiple of 4."""
+    n_rows = int(rng.randint(1, 6000))
+    n_cols = int(rng.randint(1, 9000))
+    mean = [1, 3, 9, 33, 70, 200][rng.randint(6)]
+    lens = rng.poisson(mean, size=n_rows)
+    lens[rng.rand(n_rows) < 0.1] = 0
+    if rng.rand() < 0.5:
+        lens[rng.randint(n_rows)] = int(rng.randint(500, 20000))           # a hub row
+    Ap = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(lens, out=Ap[1:])
+    nnz = int(Ap[-1])
+    rows = np.repeat(np.arange(n_rows), lens)
+    if kind_of == "band":
+        w = int(rng.randint(1, 400))
+        cols = rows * n_cols // max(n_rows, 1) + rng.randint(-w, w + 1, size=nnz)
+    elif kind_of == "bands3":
+        off = np.array([-n_cols // 3, 0, n_cols // 3])[rng.randint(3, size=nnz)]
+        cols = rows * n_cols // max(n_rows, 1) + off + rng.randint(-20, 21, size=nnz)
+    else:
+        cols = rng.randint(0, n_cols, size=nnz)
+    cols = np.clip(cols, 0, n_cols - 1).astype(np.int32)
+    if rng.rand() < 0.5:                                                   # sorted inside rows, as most files are
+        order = np.lexsort((cols, rows))
+        cols = cols[order]
+    return n_rows, n_cols, Ap, cols, nnz
+
+
+@pytest.mark.parametrize("structure", ["band", "bands3", "scatter"])
+@pytest.mark.parametrize("off,val", [("i32", "f32"), ("i64", "f64"), ("i64", "f32")])
+def test_randomized_structures(sp, oracle, structure, off, val):
+    rng = np.random.RandomState(hash((structure, off, val)) % 2 ** 31)
+    for trial in range(12):
+        n_rows, n_cols, Ap, Aj, nnz = _structured_csr(rng, structure)
+        Ap = Ap.astype(NP[off])
+        integer = trial % 3 == 0
+        if integer:
+            Ax = rng.randint(-3, 4, size=nnz).astype(NP[val])
+            x = rng.randint(-2, 3, size=n_cols).astype(NP[val])
+        else:
+            Ax = (rng.rand(nnz) * 2 - 1).astype(NP[val])
+            x = (rng.rand(n_cols) * 2 - 1).astype(NP[val])
+        for kind in KINDS:
+            y = gpu_spmv(sp, kind, n_cols, Ap, Aj, Ax, x, plan=(trial % 2 == 0))
+            assert_parity(oracle, Ap, Aj, Ax, x, y, exact=integer)
