@@ -14,6 +14,8 @@
 // (one row per vector, grid = ceil(rows / vectors per block), cusp_warp_reduce.cuh:70-87);
 // it is used only when Aj/Ax/x are not 16-byte aligned.
 
+#include <cstdlib>
+
 #include "common.hpp"
 #include "row_dot.hpp"
 #include "xwindow.hpp"
@@ -71,7 +73,17 @@ template <typename val_t> constexpr int rows_in_flight() { return sizeof(val_t) 
 void shape_vector(Plan& p) {
     p.lanes_per_row = pick_lanes_per_row(p.nnz, p.n_rows, p.elems_per_lane);
     const int R = p.val_type == MI355_VAL_F64 ? rows_in_flight<double>() : rows_in_flight<float>();
+    if (const char* e = getenv("MI355_SPMV_LANES")) {          // tuning knobs
+        const int t = atoi(e);
+        if (t == 2 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64) p.lanes_per_row = t;
+    }
     p.rows_per_chunk = pick_rows_per_chunk(p.nnz, p.n_rows, p.lanes_per_row, R);
+    if (const char* e = getenv("MI355_SPMV_ROWS_PER_CHUNK")) {
+        const int64_t pass = int64_t(kBlock / p.lanes_per_row) * R;
+        int64_t r = atoll(e);
+        r = (r + pass - 1) / pass * pass;
+        if (r >= pass && r <= kMaxChunkRows) p.rows_per_chunk = r;
+    }
     p.grid_blocks = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
     if (p.grid_blocks < 1) p.grid_blocks = 1;
     p.n_tiles = p.grid_blocks;
