@@ -96,7 +96,7 @@ struct Mapped {
         if (fstat(fd, &st) != 0) return false;
         size = size_t(st.st_size);
         if (size == 0) { data = ""; return true; }
-        void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
         if (p == MAP_FAILED) return false;
         data = static_cast<const char*>(p);
         madvise(p, size, MADV_SEQUENTIAL);
