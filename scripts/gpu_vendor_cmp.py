@@ -15,7 +15,40 @@ import __graft_entry__ as g
 sp = g.load_package()
 dev = torch.device("cuda:0")
 out = {}
-for w in (sys.argv[1:] or ["s32-band", "c2-cant", "c3-webgoogle"]):
+
+# rocSPARSE csrmv called directly (tools/cmp_rocsparse.cpp): with analysis (adaptive) and without (row split)
+CMP = os.path.join(ROOT, "tools", "bin", "libcmp_rocsparse.so")
+cmp_lib = None
+if os.path.exists(CMP) and "--no-rocsparse" not in sys.argv:
+    import ctypes
+    cmp_lib = ctypes.CDLL(CMP)
+    cmp_lib.cmp_rocsparse_csrmv.restype = ctypes.c_int
+    cmp_lib.cmp_rocsparse_csrmv.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + \
+        [ctypes.POINTER(ctypes.c_double)] * 2
+
+
+def rocsparse_direct(m, x, y_ours):
+    """{'adaptive': us, 'stream': us, 'analysis_ms': ms, 'rel_maxdiff': d} or None (64-bit offsets)."""
+    if cmp_lib is None or m.Ap.dtype != torch.int32 or m.nnz >= 2 ** 31:
+        return None
+    import ctypes
+    res = {}
+    y = torch.full_like(y_ours, float("nan"))
+    for name, analyse in (("stream", 0), ("adaptive", 1)):
+        us, ana = ctypes.c_double(0), ctypes.c_double(0)
+        torch.cuda.synchronize()
+        rc = cmp_lib.cmp_rocsparse_csrmv(0 if m.Ax.dtype == torch.float32 else 1, m.n_rows, m.n_cols, m.nnz,
+                                         m.Ap.data_ptr(), m.Aj.data_ptr(), m.Ax.data_ptr(), x.data_ptr(),
+                                         y.data_ptr(), analyse, 5, 30, ctypes.byref(us), ctypes.byref(ana))
+        assert rc == 0
+        torch.cuda.synchronize()
+        res[name + "_us"] = us.value
+        if analyse:
+            res["analysis_ms"] = ana.value
+        res[name + "_rel_maxdiff_vs_ours"] = float((y - y_ours).abs().max() / (y_ours.abs().max() + 1e-30))
+    return res
+
+for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["s32-band", "c2-cant", "c3-webgoogle"]):
     m = sp.synth.workload(w, dev)
     if m.Ap.dtype != m.Aj.dtype:
         # torch.sparse_csr_tensor does not validate index dtypes by default; int64 crow + int32 col
@@ -42,6 +75,7 @@ for w in (sys.argv[1:] or ["s32-band", "c2-cant", "c3-webgoogle"]):
         res[kind] = a.elapsed_time(b) / 30 * 1e3
         p.destroy()
     err = float((y2 - y).abs().max() / (y.abs().max() + 1e-30))
+    direct = rocsparse_direct(m, x, y2)
     for _ in range(5):
         y = A @ x
     torch.cuda.synchronize()
@@ -53,7 +87,7 @@ for w in (sys.argv[1:] or ["s32-band", "c2-cant", "c3-webgoogle"]):
     torch.cuda.synchronize()
     t = a.elapsed_time(b) / 30 * 1e3
     out[w] = {"vendor_torch_sparse_us": t, "ours_us": res, "rel_maxdiff_vs_vendor": err,
-              "algorithmic_GBps_vendor": m.algorithmic_bytes() / t / 1e3}
+              "algorithmic_GBps_vendor": m.algorithmic_bytes() / t / 1e3, "rocsparse_csrmv": direct}
     print(w, json.dumps(out[w]), flush=True)
     del A, m, x, y, y2
     torch.cuda.empty_cache()

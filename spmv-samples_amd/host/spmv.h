@@ -20,14 +20,26 @@
 #include <string>
 
 #include "spmv/mi355.hpp"
+#include "spmv/rocsparse_cmp.hpp"
 #include "timer.hpp"
+
+// Vendor comparison columns (the place of "cusparse" in the reference's list, spmv.h:19): present
+// only in a build with -DMI355_WITH_ROCSPARSE, never part of the engine.
+#ifdef MI355_WITH_ROCSPARSE
+#define SPMV_KINDS_VENDOR                             \
+    X("rocsparse", SpMV_rocsparse)                    \
+    X("rocsparse_stream", SpMV_rocsparse_stream)
+#else
+#define SPMV_KINDS_VENDOR
+#endif
 
 /// SPMV kind strings and its function
 #define SPMV_KINDS                                    \
     X("hip_vector", SpMV_hip_vector)                  \
     X("hip_merge", SpMV_hip_merge)                    \
     X("hip_light", SpMV_hip_light)                    \
-    X("hip_merge_genl", SpMV_hip_merge_generalized)
+    X("hip_merge_genl", SpMV_hip_merge_generalized)   \
+    SPMV_KINDS_VENDOR
 
 template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,
           typename vec_y_value_t>
