@@ -81,24 +81,49 @@ template <typename val_t> struct Semiring<MI355_SEMIRING_MAX_TIMES, val_t> {
 };
 
 // ---- K6: tile start coordinates ------------------------------------------------
-template <typename off_t>
+// The split of diagonal d is the first p in [lo, hi] with Ap[p + 1] > d - p - 1.  The reference finds it
+// by bisection, one thread per diagonal (thread_search.cuh:15-49): ~log2(n_rows) DEPENDENT loads, and the
+// few workgroups that hold all the diagonals issue them uncoalesced.  Here L lanes share a diagonal: one
+// probe per lane cuts the range (L+1)-fold per round (the predicate is monotone, so the number of probes
+// below the split, a popcount of the group's ballot bits, names the sub-range), the chain is
+// log_{L+1}(n_rows) + 1 loads long and the probes of a round are spread over L times as many CUs.
+// L = 16 for a few thousand diagonals (latency-bound), smaller L as the diagonals alone fill the chip
+// (L = 1 is the bisection); launch_merge picks L from the measured crossovers.
+template <int kSearchLanes, typename off_t>
 __global__ __launch_bounds__(kBlock) void merge_search_kernel(
     int32_t n_rows, int64_t nnz, const off_t* __restrict__ Ap, int64_t tile_items, int64_t n_tiles,
     int32_t* __restrict__ tile_row, int64_t* __restrict__ tile_nnz) {
-    const int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (t > n_tiles) return;
+    const int64_t gid = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t t_raw = gid / kSearchLanes;
+    const int64_t t = t_raw <= n_tiles ? t_raw : n_tiles;       // surplus groups repeat the last diagonal
+    const int k = int(gid) & (kSearchLanes - 1);
+    const int shift = (threadIdx.x & (kWave - 1)) & ~(kSearchLanes - 1);
     const int64_t items = int64_t(n_rows) + nnz;
     int64_t diag = t * tile_items;
     if (diag > items) diag = items;
     int64_t lo = diag - nnz > 0 ? diag - nnz : 0;
     int64_t hi = diag < n_rows ? diag : n_rows;
-    while (lo < hi) {
-        const int64_t p = (lo + hi) >> 1;
-        if (int64_t(Ap[p + 1]) <= diag - p - 1) lo = p + 1;
-        else hi = p;
+    while (__any(lo < hi)) {                                    // a finished group probes nothing new: c = 0
+        const int64_t n = hi - lo;
+        const bool last = n <= kSearchLanes;                    // every remaining position probed: c is the answer
+        auto probe = [&](int j) { return last ? lo + j : lo + (int64_t(j + 1) * n) / (kSearchLanes + 1); };
+        const int64_t q = probe(k);
+        const int64_t qc = q < hi ? q : hi - 1;                 // clamped into [-1, n_rows): the load is in range
+        const bool below = (q < hi) & (int64_t(Ap[qc + 1]) <= diag - qc - 1);
+        const int c = __popcll((__ballot(below) >> shift) & ((1ull << kSearchLanes) - 1));
+        if (last) {
+            lo += c;
+            hi = lo;
+        } else {
+            const int64_t new_lo = c > 0 ? probe(c - 1) + 1 : lo;
+            hi = c < kSearchLanes ? probe(c) : hi;
+            lo = new_lo;
+        }
     }
-    tile_row[t] = int32_t(lo);
-    tile_nnz[t] = diag - lo;
+    if (k == 0 && t_raw <= n_tiles) {
+        tile_row[t] = int32_t(lo);
+        tile_nnz[t] = diag - lo;
+    }
 }
 
 // ---- K7: one run of consecutive tiles per workgroup ---------------------------------
@@ -324,12 +349,15 @@ __global__ __launch_bounds__(kBlock) void merge_fixup_kernel(
     const val_t* __restrict__ carry_val, val_t* __restrict__ y, val_t alpha) {
     const int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (t >= n_carries) return;
+    // the neighbours and the value are fetched with carry_row[t]: two dependent round trips (then y[r]), not four
     const int32_t r = carry_row[t];
-    if (r >= n_rows) return;
-    if (t > 0 && carry_row[t - 1] == r) return;  // not the first run carrying row r
+    const int32_t r_prev = t > 0 ? carry_row[t - 1] : -1;
+    const int32_t r_next = t + 1 < n_carries ? carry_row[t + 1] : -1;
     val_t s = carry_val[t];
+    if (r >= n_rows || r_prev == r) return;      // no carry, or not the first run carrying row r
     using SR = Semiring<S, val_t>;
-    for (int64_t u = t + 1; u < n_carries && carry_row[u] == r; ++u) s = SR::reduce(s, carry_val[u]);
+    if (r_next == r)
+        for (int64_t u = t + 1; u < n_carries && carry_row[u] == r; ++u) s = SR::reduce(s, carry_val[u]);
     if constexpr (S == MI355_SEMIRING_PLUS_TIMES) s = alpha * s;
     y[r] = SR::reduce(y[r], s);
 }
@@ -377,9 +405,20 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
     const bool reuse = (p.flags & MI355_PLAN_REUSE_STRUCTURE) && p.coords_valid;
     if (!reuse) {
-        const unsigned g = unsigned((p.n_tiles + 1 + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL((merge_search_kernel<off_t>), dim3(g), dim3(kBlock), 0, s, p.n_rows, p.nnz, Ap,
-                           p.tile_items, p.n_tiles, p.tile_row, p.tile_nnz);
+        const int64_t diagonals = p.n_tiles + 1;
+        // measured (us, L = 1 / 4 / 16): 2 946 diagonals 7.3 / 6.0 / 4.4, 68 K 11.9 / 8.5 / 13.3, 139 K 14.0 / 16.0 / 30.9
+        static const int forced = env_int("MI355_MERGE_SEARCH_LANES", 0);
+        const int lanes = forced > 0 ? forced : diagonals <= 16384 ? 16 : diagonals <= 98304 ? 4 : 1;
+        const unsigned g = unsigned((diagonals * lanes + kBlock - 1) / kBlock);
+        if (lanes >= 16)
+            hipLaunchKernelGGL((merge_search_kernel<16, off_t>), dim3(g), dim3(kBlock), 0, s, p.n_rows, p.nnz, Ap,
+                               p.tile_items, p.n_tiles, p.tile_row, p.tile_nnz);
+        else if (lanes >= 4)
+            hipLaunchKernelGGL((merge_search_kernel<4, off_t>), dim3(g), dim3(kBlock), 0, s, p.n_rows, p.nnz, Ap,
+                               p.tile_items, p.n_tiles, p.tile_row, p.tile_nnz);
+        else
+            hipLaunchKernelGGL((merge_search_kernel<1, off_t>), dim3(g), dim3(kBlock), 0, s, p.n_rows, p.nnz, Ap,
+                               p.tile_items, p.n_tiles, p.tile_row, p.tile_nnz);
         MI355_HIP_TRY(hipGetLastError());
         p.coords_valid = true;
     }
