@@ -154,15 +154,19 @@ def cpu_baseline(m, x, budget_s):
     return out
 
 
-def read_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary, if any."""
+def read_traffic(kernel, algorithmic_bytes):
+    """HBM bytes per launch of `kernel` from the committed PMC summaries (profiles/traffic_latest.json),
+    only when a summary was taken on THIS configuration (same kernel, same algorithmic bytes)."""
     p = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(p) as f:
-            t = json.load(f)
-        return t.get(kernel, {}).get("hbm_bytes_per_launch")
+            entries = json.load(f)["entries"]
+        for e in entries:
+            if e["kernel"] == kernel and int(e["algorithmic_bytes"]) == int(algorithmic_bytes):
+                return e["hbm_bytes_per_launch"]
     except Exception:
-        return None
+        pass
+    return None
 
 
 def main():
@@ -261,7 +265,7 @@ def main():
             "compute_only": {"ms": dev_ms, "gflops_per_gpu": 2.0 * m.nnz / dev_ms / 1e6,
                              "step_ms_incl_exchange": wall / args.steps * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": read_traffic(info["main_kernel"]),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": read_traffic(info["main_kernel"], bytes_alg),
                          "kernel": info["main_kernel"], "kernel_ms": dev_ms, "algorithmic_bytes": bytes_alg},
             "warmup_probe_ms": probe,
         }

@@ -55,5 +55,15 @@ for k, d in res.items():
     if f is not None and w is not None:
         d["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
         d["hbm_bytes_formula"] = "(2*FETCH_SIZE + WRITE_SIZE) * 1024  [gfx950 FETCH_SIZE half-count correction]"
+# which bench configuration the counters belong to (bench.py only reports `traffic` for the same one)
+for name in ("bench_trace.json", "bench_fetch.json", "bench.json"):
+    try:
+        line = [l for l in open(os.path.join(out, name)).read().splitlines() if l.startswith("{")][-1]
+        b = json.loads(line)
+        res["_bench"] = {"workload": b["config"]["workload"], "kind": b["config"]["kind"],
+                         "kernel": b["roofline"]["kernel"], "algorithmic_bytes": b["roofline"]["algorithmic_bytes"]}
+        break
+    except Exception:
+        continue
 print(json.dumps(res, indent=1, sort_keys=True))
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1, sort_keys=True)

@@ -30,7 +30,7 @@ static int plan_alloc_scratch(Plan& p) {
         o_carry_row = off; off = align_up(off + sizeof(int32_t) * size_t(p.n_tiles + 1), 256);
         o_carry_val = off; off = align_up(off + val_bytes * size_t(p.n_tiles + 1), 256);
     } else if (p.kind == MI355_KIND_LIGHT) {
-        o_counters = off;  off = align_up(off + 128 * size_t(kXcds), 256);
+        o_counters = off;  off = align_up(off + 128 * size_t(kXcds + 1), 256);   // 8 shards + the leavers' count
     }
     p.scratch_bytes = off;
     p.scratch = nullptr;
@@ -42,6 +42,10 @@ static int plan_alloc_scratch(Plan& p) {
         p.carry_row = reinterpret_cast<int32_t*>(base + o_carry_row);
         p.carry_val = base + o_carry_val;
         p.counters = reinterpret_cast<unsigned long long*>(base + o_counters);
+        if (p.kind == MI355_KIND_LIGHT) {   // zero once; the kernel re-arms the counters at the end of every execute
+            MI355_HIP_TRY(hipMemset(p.counters, 0, 128 * size_t(kXcds + 1)));
+            MI355_HIP_TRY(hipStreamSynchronize(nullptr));   // the first execute may come on any stream
+        }
     }
     return MI355_SPMV_OK;
 }

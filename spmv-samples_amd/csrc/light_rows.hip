@@ -20,15 +20,19 @@
 //    through LDS + barrier; all lanes stay in the loops and rows past the chunk are
 //    predicated (the reference's warp-level kernel lets finished vectors leave a
 //    loop whose siblings still shuffle, LightSpMV.cuh:212, :246, :260);
-//  * the counters live in the plan's scratch and are zeroed by a memset node on
-//    the stream each call (the reference mallocs, memsets and frees them per call,
-//    LightSpMV.cuh:274-276, :314);
+//  * the counters live in the plan's scratch, zeroed once at plan creation, and are
+//    RE-ARMED BY THE KERNEL: the last workgroup to leave (a ninth counter counts the
+//    leavers) stores zeros, so an execute is a single launch with no memset in front
+//    of it and can be captured in a hipGraph (the reference mallocs, memsets and frees
+//    the counter per call, LightSpMV.cuh:274-276, :314).  A plan therefore serves one
+//    stream at a time;
 //  * x is read with plain loads / the LDS window (no texture path on CDNA; the
 //    reference's texture fetch, LightSpMV.cuh:59-88, has no counterpart).
 //
-// Exit condition: a workgroup leaves after visiting all 8 shards; a visit ends on
-// the first dequeue at or past the shard's end, which every workgroup reaches
-// whatever the interleaving, so the grid always drains.
+// Exit condition: a workgroup drains its own shard, asks once which other shards still
+// hold rows, visits those and leaves; a visit ends on the first dequeue at or past the
+// shard's end, which every workgroup reaches whatever the interleaving, so the grid
+// always drains.
 
 #include <cstdlib>
 
@@ -46,6 +50,37 @@ __device__ __forceinline__ unsigned long long wave_broadcast_u64(unsigned long l
     return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
+
+// Bit s set = shard s still had rows to hand out a moment ago.  Called by a whole wave: lanes 0..7 read
+// the eight counters with one returning atomic each, in flight together, so a workgroup whose own shard
+// ran dry pays ONE round trip to learn which other shards are worth a visit instead of one failed
+// dequeue (a dependent ~2 us round trip) per shard.  A counter only grows during an execute, so "dry" is
+// final; a shard reported busy is visited and drained with ordinary dequeues.
+__device__ __forceinline__ unsigned shards_with_rows(unsigned long long* __restrict__ counters, int32_t n_rows) {
+    const int lane = threadIdx.x & (kWave - 1);
+    bool has = false;
+    if (lane < kXcds) {
+        const int64_t size = int64_t(n_rows) * (lane + 1) / kXcds - int64_t(n_rows) * lane / kXcds;
+        has = int64_t(atomicAdd(&counters[lane * kCounterStride], 0ull)) < size;
+    }
+    return unsigned(__ballot(has)) & ((1u << kXcds) - 1u);
+}
+
+// The workgroup has made its last dequeue (on every shard it visited one returned past the shard's end,
+// and the issuing thread waited for every returned value).  The last of the gridDim.x workgroups to get here re-arms
+// the counters for the next execute.
+__device__ __forceinline__ void light_leave(unsigned long long* __restrict__ counters) {
+    __syncthreads();
+    // Relaxed device-scope atomics are enough (and a fence here would write the XCD's L2 back, +10 us):
+    // the counters are only ever touched by atomics, and this thread has consumed the value returned by
+    // every dequeue it issued, so they all precede this increment.
+    if (threadIdx.x == 0) {
+        const unsigned long long left = atomicAdd(&counters[kXcds * kCounterStride], 1ull);
+        if (left == gridDim.x - 1)
+            for (int i = 0; i <= kXcds; ++i) atomicExch(&counters[i * kCounterStride], 0ull);
+    }
+}
+
 template <int T, int R, int NSEG, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
@@ -55,12 +90,23 @@ __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2 * (kBlock / kWave)];
     __shared__ unsigned long long s_got;
+    __shared__ unsigned s_busy;
     ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, rows_per_chunk);
     scr.alpha = alpha;
     scr.beta = beta;
     const int home = blockIdx.x % kXcds;
+    unsigned busy = 1u << home;
     for (int visit = 0; visit < kXcds; ++visit) {
         const int shard = (home + visit) % kXcds;
+        if (visit == 1) {   // own shard dry: ask the others once, all at the same time
+            if (threadIdx.x < kWave) {
+                const unsigned b = shards_with_rows(counters, n_rows);
+                if (threadIdx.x == 0) s_busy = b;
+            }
+            __syncthreads();
+            busy = s_busy;
+        }
+        if (!((busy >> shard) & 1u)) continue;      // uniform over the workgroup
         const int64_t shard_begin = int64_t(n_rows) * shard / kXcds;
         const int64_t shard_end = int64_t(n_rows) * (shard + 1) / kXcds;
         while (true) {
@@ -86,6 +132,7 @@ __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
         }
         __syncthreads();      // s_got read by all before the next shard's dequeue overwrites it
     }
+    light_leave(counters);
 }
 
 // 4-byte-per-lane form for operands that are not 16-byte aligned: one dequeue per wave.
@@ -99,8 +146,11 @@ __global__ __launch_bounds__(kBlock) void light_rows_kernel(
     const int lane = threadIdx.x & (T - 1);
     const int vec_in_wave = lane64 / T;
     const int home = blockIdx.x % kXcds;
+    unsigned busy = 1u << home;
     for (int visit = 0; visit < kXcds; ++visit) {
         const int shard = (home + visit) % kXcds;
+        if (visit == 1) busy = shards_with_rows(counters, n_rows);
+        if (!((busy >> shard) & 1u)) continue;      // wave-uniform
         const int64_t shard_begin = int64_t(n_rows) * shard / kXcds;
         const int64_t shard_end = int64_t(n_rows) * (shard + 1) / kXcds;
         while (true) {
@@ -126,6 +176,7 @@ __global__ __launch_bounds__(kBlock) void light_rows_kernel(
             }
         }
     }
+    light_leave(counters);
 }
 
 template <typename val_t> constexpr int light_rows_in_flight() { return sizeof(val_t) == 4 ? 4 : 2; }
@@ -231,7 +282,6 @@ static int launch_light_plain(const Plan& p, const off_t* Ap, const val_t* Ax, c
 template <typename off_t, typename val_t>
 int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s) {
     if (p.n_rows == 0) return MI355_SPMV_OK;
-    MI355_HIP_TRY(hipMemsetAsync(p.counters, 0, sizeof(unsigned long long) * kCounterStride * kXcds, s));
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
     if (aligned && p.nnz >= 4) return launch_light_window<off_t, val_t>(p, Ap, Ax, x, y, s);

@@ -236,6 +236,39 @@ def test_execute_on_a_side_stream(sp, oracle, kind):
     p.destroy()
 
 
+@pytest.mark.parametrize("kind", KINDS)
+def test_execute_is_capturable_in_a_hip_graph(sp, oracle, kind):
+    """plan_execute only enqueues (kernels + one memset for `light`): it can be captured once and
+    replayed, the way the 2000-iteration loop of main.cu:102-113 would be run launch-free.  The
+    replay reads the operands where they were at capture time, so new x values are copied in place."""
+    rng = np.random.RandomState(37)
+    Ap, Aj, Ax = random_csr(rng, 6000, 800, 24, long_row=9000)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    dAp, dAj, dAx = d(Ap), d(Aj), d(Ax)
+    dx = torch.zeros(800, device=DEV)
+    y = torch.full((6000,), float("nan"), device=DEV)
+    p = sp.Plan(kind, 6000, 800, int(Ap[-1]), dAp, dAj, torch.float32)
+    p.execute(dAx, dx, y)                      # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        p.execute(dAx, dx, y)
+    for seed in (1, 2, 3):
+        x = (np.random.RandomState(seed).rand(800) * 2 - 1).astype(np.float32)
+        dx.copy_(torch.from_numpy(x))
+        y.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        got = y.cpu().numpy()
+        assert_parity(oracle, Ap, Aj, Ax, x, got)
+        y2 = torch.full_like(y, float("nan"))
+        p.execute(dAx, dx, y2)                 # the replay and a direct launch give the same bits
+        torch.cuda.synchronize()
+        assert np.array_equal(got, y2.cpu().numpy())
+    del g
+    p.destroy()
+
+
 # ---- BASELINE-sized inputs ---------------------------------------------------------------------
 
 @pytest.mark.parametrize("kind", KINDS)
