@@ -156,6 +156,10 @@ typedef struct mi355_spmv_plan_info {
     int32_t window_elems;     /* elements of x staged through LDS per workgroup (0 = none) */
     int32_t window_segments;  /* 1 = one window; 2..4 = that many column bands staged side by side */
     char main_kernel[64];     /* substring of the dominant kernel's symbol name    */
+    int32_t balanced_chunks;  /* VECTOR, LIGHT: 1 = row chunks cut by weight (nonzeros + mean row length per
+                                 row) because equal-row chunks were uneven, 0 = equal-row chunks           */
+    int32_t rows_cap;         /* VECTOR, LIGHT: most rows a chunk can hold                                 */
+    int64_t n_chunks;         /* VECTOR, LIGHT: row chunks                                                 */
 } mi355_spmv_plan_info;
 int mi355_spmv_plan_get_info(const mi355_spmv_plan* plan, mi355_spmv_plan_info* info);
 

@@ -2,7 +2,7 @@
 # parity suite under forced code paths (window on/off, sampled vs band-placed window, no segments)
 mkdir -p gpurun_out
 rc=0
-for env in "MI355_SPMV_WINDOW=1" "MI355_SPMV_WINDOW=0" "MI355_SPMV_WINDOW_FROM_BAND=0" "MI355_SPMV_SEGMENTS=0" "MI355_MERGE_TPS=1" "MI355_MERGE_TPS=5" "MI355_MERGE_SEARCH_LANES=1" "MI355_MERGE_SEARCH_LANES=4"; do
+for env in "MI355_SPMV_WINDOW=1" "MI355_SPMV_WINDOW=0" "MI355_SPMV_WINDOW_FROM_BAND=0" "MI355_SPMV_SEGMENTS=0" "MI355_MERGE_TPS=1" "MI355_MERGE_TPS=5" "MI355_MERGE_SEARCH_LANES=1" "MI355_MERGE_SEARCH_LANES=4" "MI355_SPMV_BALANCE=1" "MI355_SPMV_BALANCE=0"; do
   env $env timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/pt_env.log 2>&1
   r=$?
   echo "$env : exit $r : $(tail -1 gpurun_out/pt_env.log)"

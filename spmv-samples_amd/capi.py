@@ -38,7 +38,8 @@ class PlanInfo(C.Structure):
                 ("lanes_per_row", C.c_int32), ("elems_per_lane", C.c_int32), ("block_threads", C.c_int32),
                 ("grid_blocks", C.c_int64), ("tile_items", C.c_int64), ("n_tiles", C.c_int64),
                 ("rows_per_chunk", C.c_int64), ("scratch_bytes", C.c_int64), ("n_kernels", C.c_int32),
-                ("window_elems", C.c_int32), ("window_segments", C.c_int32), ("main_kernel", C.c_char * 64)]
+                ("window_elems", C.c_int32), ("window_segments", C.c_int32), ("main_kernel", C.c_char * 64),
+                ("balanced_chunks", C.c_int32), ("rows_cap", C.c_int32), ("n_chunks", C.c_int64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}

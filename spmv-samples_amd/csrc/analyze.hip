@@ -102,6 +102,129 @@ int probe_structure(Plan& p) {
     return MI355_SPMV_OK;
 }
 
+// ---- uniform or nnz-balanced chunks (VECTOR, LIGHT) ---------------------------------------------
+// Chunks of equal ROW count are right for matrices whose rows are alike (the S32-band target, FEM
+// matrices, stencils): no table, no extra load.  On a power-law matrix they are not: the 2 048 rows
+// that hold the hubs of the web-Google stand-in carry 8 % of all nonzeros, one workgroup walks them
+// while the chip idles (vector 763 us, light 575 us vs merge 49 us; R-MAT-24: 20.4 / 14.4 ms vs 2.4 ms).
+// The plan therefore measures the heaviest uniform chunk once (two reads of Ap per chunk) and, when it is
+// more than twice the mean,
+// cuts the rows by WEIGHT instead: a row weighs (its nonzeros + k), k = mean row length, and chunk c
+// starts at the first row r with Ap[r] + k r >= c Q.  That is the merge-path diagonal cut with rows
+// weighted k instead of 1 (thread_search.cuh:15-49) at chunk granularity: a chunk holds at most Q / k rows
+// and at most Q nonzeros plus one row's overshoot, and the boundaries come from a binary search per
+// chunk at plan creation (chunk_table_kernel) instead of a per-launch search kernel.
+template <typename off_t>
+__global__ __launch_bounds__(kBlock) void chunk_max_kernel(int32_t n_rows, const off_t* __restrict__ Ap,
+                                                           int64_t rows_per_chunk, int64_t n_chunks,
+                                                           unsigned long long* out) {
+    unsigned long long m = 0;
+    for (int64_t c = int64_t(blockIdx.x) * kBlock + threadIdx.x; c < n_chunks; c += int64_t(gridDim.x) * kBlock) {
+        const int64_t rb = c * rows_per_chunk;
+        const int64_t re = min(rb + rows_per_chunk, int64_t(n_rows));
+        const unsigned long long w = (unsigned long long)(Ap[re] - Ap[rb]);
+        m = w > m ? w : m;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long other = __shfl_xor(m, o, kWave);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(out, m);
+}
+
+template <typename off_t>
+__global__ __launch_bounds__(kBlock) void chunk_table_kernel(int32_t n_rows, const off_t* __restrict__ Ap, int64_t k,
+                                                             int64_t q, int64_t n_chunks,
+                                                             int32_t* __restrict__ chunk_row) {
+    const int64_t c = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (c > n_chunks) return;
+    if (c == n_chunks) {
+        chunk_row[c] = n_rows;
+        return;
+    }
+    const int64_t target = c * q;            // first r in [0, n_rows] with Ap[r] + k r >= target
+    int64_t lo = 0, hi = n_rows;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (int64_t(Ap[mid]) + k * mid >= target) hi = mid;
+        else lo = mid + 1;
+    }
+    chunk_row[c] = int32_t(lo & ~int64_t(3));   // multiples of 4 rows keep the y sweep on 16-byte stores
+}
+
+int long_steps_for(const Plan& p) {
+    static const int forced = [] { const char* e = getenv("MI355_SPMV_LONG_STEPS"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced;
+    // measured on the power-law stand-ins (us, 1 / 2 / 4 / 8 / 16 steps): web-Google 139 / 120 / 99 / 104 / 105,
+    // R-MAT-24 light 2 820 at 4 vs 3 200 at 16; uniform plans keep the long chain (their rows rarely need it)
+    return p.balanced ? 4 : kLongSteps;
+}
+
+int decide_balance(Plan& p) {
+    p.balanced = false;
+    p.chunk_row = nullptr;
+    p.rows_cap = int(p.rows_per_chunk);
+    p.n_chunks = p.rows_per_chunk > 0 ? (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk : 0;
+    if (p.n_chunks < 1) p.n_chunks = 1;
+    const char* ev = getenv("MI355_SPMV_BALANCE");          // 0 = never, 1 = always, unset = measure
+    if (p.n_rows <= 0 || p.nnz <= 0 || (ev && atoi(ev) == 0)) return MI355_SPMV_OK;
+    bool want = ev && atoi(ev) != 0;
+    if (!want && p.n_chunks >= 2) {
+        unsigned long long* d_max = nullptr;
+        MI355_HIP_TRY(hipMalloc(&d_max, sizeof(unsigned long long)));
+        hipError_t e = hipMemset(d_max, 0, sizeof(unsigned long long));
+        const unsigned g = unsigned(std::min<int64_t>((p.n_chunks + kBlock - 1) / kBlock, 1024));
+        if (e == hipSuccess) {
+            if (p.off_type == MI355_OFF_I32)
+                hipLaunchKernelGGL((chunk_max_kernel<int32_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
+                                   static_cast<const int32_t*>(p.Ap), p.rows_per_chunk, p.n_chunks, d_max);
+            else
+                hipLaunchKernelGGL((chunk_max_kernel<int64_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
+                                   static_cast<const int64_t*>(p.Ap), p.rows_per_chunk, p.n_chunks, d_max);
+            e = hipGetLastError();
+        }
+        unsigned long long h_max = 0;
+        if (e == hipSuccess) e = hipMemcpy(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost);   // synchronises
+        (void)hipFree(d_max);
+        if (e != hipSuccess) {
+            set_error("decide_balance: %s", hipGetErrorString(e));
+            return MI355_SPMV_EHIP;
+        }
+        const double mean = double(p.nnz) / double(p.n_chunks);
+        want = double(h_max) > 2.0 * mean + 1024.0;
+    }
+    if (!want) return MI355_SPMV_OK;
+    // chunk weight: twice what a chunk of rows_per_chunk mean rows weighs, rows capped so that the LDS
+    // layout (bounds + results of rows_cap rows) stays what a uniform plan of kMaxChunkRows rows takes
+    int64_t r0 = p.rows_per_chunk;
+    if (r0 > kMaxChunkRows / 2) r0 = kMaxChunkRows / 2;
+    if (r0 < 4) r0 = 4;
+    p.bal_k = (p.nnz + p.n_rows - 1) / p.n_rows;
+    if (p.bal_k < 1) p.bal_k = 1;
+    p.bal_q = 2 * p.bal_k * r0;
+    const int64_t weight = p.nnz + p.bal_k * int64_t(p.n_rows);
+    p.n_chunks = (weight + p.bal_q - 1) / p.bal_q;
+    if (p.n_chunks < 1) p.n_chunks = 1;
+    p.rows_cap = int(2 * r0 + 4);              // Q / k rows, + 3 for the round-down of the boundaries
+    p.balanced = true;
+    return MI355_SPMV_OK;
+}
+
+int build_chunk_table(Plan& p) {
+    if (!p.balanced) return MI355_SPMV_OK;
+    const unsigned g = unsigned((p.n_chunks + 1 + kBlock - 1) / kBlock);
+    if (p.off_type == MI355_OFF_I32)
+        hipLaunchKernelGGL((chunk_table_kernel<int32_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
+                           static_cast<const int32_t*>(p.Ap), p.bal_k, p.bal_q, p.n_chunks, p.chunk_row);
+    else
+        hipLaunchKernelGGL((chunk_table_kernel<int64_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
+                           static_cast<const int64_t*>(p.Ap), p.bal_k, p.bal_q, p.n_chunks, p.chunk_row);
+    MI355_HIP_TRY(hipGetLastError());
+    MI355_HIP_TRY(hipStreamSynchronize(nullptr));   // the first execute may come on any stream
+    return MI355_SPMV_OK;
+}
+
 // Cluster the sampled offsets into bands: a gap wider than the rows a workgroup owns starts a
 // new band (splitting costs `rows` extra columns per band, keeping the gap costs the gap).
 // Returns the columns a workgroup would have to hold: sum of (band width + rows).

@@ -32,6 +32,8 @@ static int plan_alloc_scratch(Plan& p) {
     } else if (p.kind == MI355_KIND_LIGHT) {
         o_counters = off;  off = align_up(off + 128 * size_t(kXcds + 1), 256);   // 8 shards + the leavers' count
     }
+    size_t o_chunk_row = 0;
+    if (p.balanced) { o_chunk_row = off; off = align_up(off + sizeof(int32_t) * size_t(p.n_chunks + 1), 256); }
     p.scratch_bytes = off;
     p.scratch = nullptr;
     if (off) {
@@ -42,6 +44,7 @@ static int plan_alloc_scratch(Plan& p) {
         p.carry_row = reinterpret_cast<int32_t*>(base + o_carry_row);
         p.carry_val = base + o_carry_val;
         p.counters = reinterpret_cast<unsigned long long*>(base + o_counters);
+        if (p.balanced) p.chunk_row = reinterpret_cast<int32_t*>(base + o_chunk_row);
         if (p.kind == MI355_KIND_LIGHT) {   // zero once; the kernel re-arms the counters at the end of every execute
             MI355_HIP_TRY(hipMemset(p.counters, 0, 128 * size_t(kXcds + 1)));
             MI355_HIP_TRY(hipStreamSynchronize(nullptr));   // the first execute may come on any stream
@@ -160,8 +163,19 @@ int mi355_spmv_plan_create(mi355_spmv_plan** out, int kind, int off_type, int va
         case MI355_KIND_MERGE:  shape_merge(p); break;
         case MI355_KIND_LIGHT:  shape_light(p); break;
     }
-    const int st = plan_alloc_scratch(p);
-    if (st != MI355_SPMV_OK) { delete h; return st; }
+    if (kind == MI355_KIND_VECTOR || kind == MI355_KIND_LIGHT) {
+        const int st = decide_balance(p);    // heaviest uniform chunk vs the mean (synchronises)
+        if (st != MI355_SPMV_OK) { delete h; return st; }
+        if (kind == MI355_KIND_VECTOR) reshape_vector_balanced(p);
+        else reshape_light_balanced(p);
+    }
+    int st = plan_alloc_scratch(p);
+    if (st == MI355_SPMV_OK) st = build_chunk_table(p);
+    if (st != MI355_SPMV_OK) {
+        if (p.scratch) (void)hipFree(p.scratch);
+        delete h;
+        return st;
+    }
     *out = h;
     return MI355_SPMV_OK;
 }
@@ -243,6 +257,9 @@ int mi355_spmv_plan_get_info(const mi355_spmv_plan* h, mi355_spmv_plan_info* inf
     info->window_elems = p.window_elems;
     info->window_segments = p.window_elems > 0 ? (p.n_seg >= 2 ? p.n_seg : 1) : 0;
     snprintf(info->main_kernel, sizeof(info->main_kernel), "%s", p.main_kernel);
+    info->balanced_chunks = p.balanced ? 1 : 0;
+    info->rows_cap = p.rows_cap;
+    info->n_chunks = p.n_chunks;
     return MI355_SPMV_OK;
 }
 

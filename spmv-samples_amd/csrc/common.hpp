@@ -66,8 +66,13 @@ struct Plan {
     int64_t seg_lo[4], seg_hi[4];
     int probe_n;                 // sampled (column - row) offsets, sorted ascending
     int64_t probe_off[8192];
-    // dynamic rows
-    int64_t rows_per_chunk;
+    // row chunks of VECTOR / LIGHT
+    int64_t rows_per_chunk;     // uniform plan: every chunk has this many rows
+    bool balanced;              // nnz-balanced plan: chunk c = rows [chunk_row[c], chunk_row[c+1])
+    int64_t n_chunks;
+    int rows_cap;               // rows the LDS layout of a workgroup holds (>= any chunk)
+    int64_t bal_k, bal_q;       // a row weighs (its nonzeros + bal_k), a chunk holds <= bal_q of weight
+    int32_t* chunk_row;         // [n_chunks + 1], device (balanced plans only)
     // scratch
     void* scratch;
     size_t scratch_bytes;
@@ -91,8 +96,13 @@ int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x
 int probe_structure(Plan& p);
 int pick_window_elems(Plan& p, int64_t rows_per_workgroup);
 int64_t segment_rows_fit(const Plan& p);
+int long_steps_for(const Plan& p);   // steps of its vector after which a row is left to the long-row pass
+int decide_balance(Plan& p);       // VECTOR / LIGHT, after shape_*: uniform or nnz-balanced chunks
+int build_chunk_table(Plan& p);    // after the scratch is allocated
 void shape_vector(Plan& p);
 void shape_merge(Plan& p);
 void shape_light(Plan& p);
+void reshape_vector_balanced(Plan& p);
+void reshape_light_balanced(Plan& p);
 
 }  // namespace mi355

@@ -22,28 +22,30 @@
 
 namespace mi355 {
 
-template <int T, int R, int NSEG, typename off_t, typename val_t>
+template <int T, int R, int NSEG, bool ADAPT, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void csr_vector_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
-    const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, int32_t rows_per_chunk,
+    const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, ChunkMap cmap,
     int32_t window_cap, BandHint hint, SegmentPlan segs, val_t alpha, val_t beta) {
     // NSEG: 0 = no window (plain gathers), 1 = one window of x in LDS, kMaxSegments = several bands
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2 * (kBlock / kWave)];
-    ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, rows_per_chunk);
+    ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, cmap.rows_cap);
     scr.alpha = alpha;
     scr.beta = beta;
+    scr.long_steps = cmap.long_steps;
     const unsigned chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int64_t rb = int64_t(chunk) * rows_per_chunk;
-    const int64_t re = min(rb + rows_per_chunk, int64_t(n_rows));
+    int64_t rb, re;
+    cmap.range(chunk, n_rows, rb, re);
+    if (rb >= re) return;   // (balanced plans: a hub row heavier than a chunk leaves empty chunks behind it)
     stage_chunk_bounds<off_t, val_t>(scr, rb, re, Ap);      // ordered before chunk_rows by the barrier below
     if constexpr (NSEG > 1) {
         const XWindowN<val_t> win = stage_x_segments<val_t>(rb, re, n_cols, x, scr.s_x, window_cap, segs);
-        chunk_rows<T, R, true, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
+        chunk_rows_any<T, R, true, ADAPT, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
     } else {
         const XWindow<val_t> win =
             stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
-        chunk_rows<T, R, NSEG == 1, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
+        chunk_rows_any<T, R, NSEG == 1, ADAPT, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
     }
 }
 
@@ -100,6 +102,15 @@ void shape_vector(Plan& p) {
     snprintf(p.main_kernel, sizeof(p.main_kernel), "csr_vector_window_kernel");
 }
 
+// after decide_balance: one workgroup per chunk, window sized for the rows a chunk may hold
+void reshape_vector_balanced(Plan& p) {
+    if (!p.balanced) return;
+    p.grid_blocks = p.n_chunks;
+    p.n_tiles = p.n_chunks;
+    p.window_elems = pick_window_elems(p, p.rows_cap);
+    if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }   // (the multi-band plan is sized for uniform chunks)
+}
+
 template <typename off_t, typename val_t>
 static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
                                 hipStream_t s) {
@@ -107,20 +118,29 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
     const dim3 grid((unsigned)p.grid_blocks), block(kBlock);
     const off_t nnz = (off_t)p.nnz;
-    const size_t lds = chunk_lds_bytes(p.window_elems, int(p.rows_per_chunk), sizeof(off_t), sizeof(val_t));
+    const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(off_t), sizeof(val_t));
+    const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, long_steps_for(p)};
     SegmentPlan segs;
     segs.n = p.n_seg;
     for (int i = 0; i < kMaxSegments; ++i) { segs.lo[i] = p.seg_lo[i]; segs.hi[i] = p.seg_hi[i]; }
-#define MI355_VEC_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, (int32_t)p.rows_per_chunk, (int32_t)p.window_elems, hint, segs, (val_t)p.alpha, (val_t)p.beta
+#define MI355_VEC_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, cmap, (int32_t)p.window_elems, hint, segs, (val_t)p.alpha, (val_t)p.beta
 #define MI355_VEC_CASE(TT)                                                                                   \
     case TT:                                                                                                 \
         if (p.window_elems > 0 && p.n_seg >= 2)                                                              \
-            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, kMaxSegments, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS); \
+            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, kMaxSegments, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS); \
         else if (p.window_elems > 0)                                                                         \
-            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, 1, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
+            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, 1, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
         else                                                                                                 \
-            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, 0, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
+            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, 0, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
         break;
+    if (p.balanced) {   // vector width per chunk (chunk_rows_any); the T of the template is not used
+        if (p.window_elems > 0)
+            hipLaunchKernelGGL((csr_vector_window_kernel<2, R, 1, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);
+        else
+            hipLaunchKernelGGL((csr_vector_window_kernel<2, R, 0, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);
+        MI355_HIP_TRY(hipGetLastError());
+        return MI355_SPMV_OK;
+    }
     switch (p.lanes_per_row) {
         MI355_VEC_CASE(2)
         MI355_VEC_CASE(4)

@@ -6,14 +6,15 @@
 // very different lengths balance across the chip.
 //
 // What changes for MI355X:
-//  * the unit handed out by one atomic is a CHUNK of consecutive rows taken by a
+//  * the unit handed out by one atomic is a CHUNK of consecutive rows (equal row counts,
+//    or equal weight on a power-law matrix: analyze.hip, decide_balance) taken by a
 //    whole workgroup (the reference hands 1 row to a vector or 32/T rows to a warp,
 //    LightSpMV.cuh:128-132, :205-209).  One returning device-scope atomic on a
 //    single word saturates near 88 dequeues/us on this chip; 1 row per atomic would
 //    cost ~10^5 us for 8.3 M rows.  A chunk also gives the workgroup a window of x
 //    worth staging through LDS (xwindow.hpp), which is what lifts the gather limit;
 //  * the counter is SHARDED: 8 counters, each on its own 128-byte line, each
-//    covering one contiguous eighth of the rows.  A workgroup starts on the shard of
+//    covering one contiguous eighth of the chunks.  A workgroup starts on the shard of
 //    its XCD (blockIdx % 8 shares an L2) and walks the other shards when its own
 //    runs dry, so placement only affects speed, never results;
 //  * lane 0 of the workgroup dequeues, the chunk index reaches the other waves
@@ -56,11 +57,11 @@ __device__ __forceinline__ unsigned long long wave_broadcast_u64(unsigned long l
 // ran dry pays ONE round trip to learn which other shards are worth a visit instead of one failed
 // dequeue (a dependent ~2 us round trip) per shard.  A counter only grows during an execute, so "dry" is
 // final; a shard reported busy is visited and drained with ordinary dequeues.
-__device__ __forceinline__ unsigned shards_with_rows(unsigned long long* __restrict__ counters, int32_t n_rows) {
+__device__ __forceinline__ unsigned shards_with_rows(unsigned long long* __restrict__ counters, int64_t n_units) {
     const int lane = threadIdx.x & (kWave - 1);
     bool has = false;
     if (lane < kXcds) {
-        const int64_t size = int64_t(n_rows) * (lane + 1) / kXcds - int64_t(n_rows) * lane / kXcds;
+        const int64_t size = n_units * (lane + 1) / kXcds - n_units * lane / kXcds;
         has = int64_t(atomicAdd(&counters[lane * kCounterStride], 0ull)) < size;
     }
     return unsigned(__ballot(has)) & ((1u << kXcds) - 1u);
@@ -81,52 +82,56 @@ __device__ __forceinline__ void light_leave(unsigned long long* __restrict__ cou
     }
 }
 
-template <int T, int R, int NSEG, typename off_t, typename val_t>
+template <int T, int R, int NSEG, bool ADAPT, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
-    unsigned long long* __restrict__ counters, int32_t rows_per_chunk, int32_t window_cap, BandHint hint,
+    unsigned long long* __restrict__ counters, ChunkMap cmap, int32_t window_cap, BandHint hint,
     SegmentPlan segs, val_t alpha, val_t beta) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2 * (kBlock / kWave)];
     __shared__ unsigned long long s_got;
     __shared__ unsigned s_busy;
-    ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, rows_per_chunk);
+    ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, cmap.rows_cap);
     scr.alpha = alpha;
     scr.beta = beta;
+    scr.long_steps = cmap.long_steps;
     const int home = blockIdx.x % kXcds;
     unsigned busy = 1u << home;
     for (int visit = 0; visit < kXcds; ++visit) {
         const int shard = (home + visit) % kXcds;
         if (visit == 1) {   // own shard dry: ask the others once, all at the same time
             if (threadIdx.x < kWave) {
-                const unsigned b = shards_with_rows(counters, n_rows);
+                const unsigned b = shards_with_rows(counters, cmap.n_chunks);
                 if (threadIdx.x == 0) s_busy = b;
             }
             __syncthreads();
             busy = s_busy;
         }
         if (!((busy >> shard) & 1u)) continue;      // uniform over the workgroup
-        const int64_t shard_begin = int64_t(n_rows) * shard / kXcds;
-        const int64_t shard_end = int64_t(n_rows) * (shard + 1) / kXcds;
+        const int64_t shard_begin = cmap.n_chunks * shard / kXcds;          // in chunks
+        const int64_t shard_end = cmap.n_chunks * (shard + 1) / kXcds;
         while (true) {
-            if (threadIdx.x == 0) {
-                s_got = atomicAdd(&counters[shard * kCounterStride], (unsigned long long)rows_per_chunk);
-            }
+            if (threadIdx.x == 0) s_got = atomicAdd(&counters[shard * kCounterStride], 1ull);
             __syncthreads();
-            const int64_t chunk_begin = shard_begin + int64_t(wave_broadcast_u64(s_got));
-            if (chunk_begin >= shard_end) break;  // uniform over the workgroup
-            const int64_t chunk_end = min(chunk_begin + rows_per_chunk, shard_end);
+            const int64_t chunk = shard_begin + int64_t(wave_broadcast_u64(s_got));
+            if (chunk >= shard_end) break;  // uniform over the workgroup
+            int64_t chunk_begin, chunk_end;
+            cmap.range(chunk, n_rows, chunk_begin, chunk_end);
+            if (chunk_begin >= chunk_end) {   // a hub row heavier than a chunk leaves empty chunks behind it
+                __syncthreads();              // s_got read by all before the next dequeue overwrites it
+                continue;
+            }
             // (stage_x_window's barriers also order this read of s_got before the next write)
             stage_chunk_bounds<off_t, val_t>(scr, chunk_begin, chunk_end, Ap);   // before the barrier below
             if constexpr (NSEG > 1) {
                 const XWindowN<val_t> win =
                     stage_x_segments<val_t>(chunk_begin, chunk_end, n_cols, x, scr.s_x, window_cap, segs);
-                chunk_rows<T, R, true, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+                chunk_rows_any<T, R, true, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
             } else {
                 const XWindow<val_t> win = stage_x_window<off_t, val_t>(
                     chunk_begin, chunk_end, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
-                chunk_rows<T, R, NSEG == 1, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+                chunk_rows_any<T, R, NSEG == 1, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
             }
             __syncthreads();  // every wave is done with the window before it is refilled
         }
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void light_rows_kernel(
     unsigned busy = 1u << home;
     for (int visit = 0; visit < kXcds; ++visit) {
         const int shard = (home + visit) % kXcds;
-        if (visit == 1) busy = shards_with_rows(counters, n_rows);
+        if (visit == 1) busy = shards_with_rows(counters, n_rows);   // (this kernel's unit is the row)
         if (!((busy >> shard) & 1u)) continue;      // wave-uniform
         const int64_t shard_begin = int64_t(n_rows) * shard / kXcds;
         const int64_t shard_end = int64_t(n_rows) * (shard + 1) / kXcds;
@@ -214,6 +219,18 @@ void shape_light(Plan& p) {
     snprintf(p.main_kernel, sizeof(p.main_kernel), "light_rows_window_kernel");
 }
 
+// after decide_balance: the persistent grid is sized by the chunks there are, window by the rows a chunk may hold
+void reshape_light_balanced(Plan& p) {
+    if (!p.balanced) return;
+    p.n_tiles = p.n_chunks;
+    p.window_elems = pick_window_elems(p, p.rows_cap);
+    if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }
+    const char* er = getenv("MI355_LIGHT_BLOCKS_PER_CU");
+    const int64_t resident = int64_t(kCus) * (er && atoi(er) > 0 ? atoi(er) : (p.window_elems ? 4 : 5));
+    p.grid_blocks = p.n_chunks < resident ? p.n_chunks : resident;
+    if (p.grid_blocks < 1) p.grid_blocks = 1;
+}
+
 template <typename off_t, typename val_t>
 static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
                                hipStream_t s) {
@@ -221,21 +238,29 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
     const dim3 grid((unsigned)p.grid_blocks), block(kBlock);
     const off_t nnz = (off_t)p.nnz;
-    const int32_t chunk = (int32_t)p.rows_per_chunk;
-    const size_t lds = chunk_lds_bytes(p.window_elems, chunk, sizeof(off_t), sizeof(val_t));
+    const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, long_steps_for(p)};
+    const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(off_t), sizeof(val_t));
     SegmentPlan segs;
     segs.n = p.n_seg;
     for (int i = 0; i < kMaxSegments; ++i) { segs.lo[i] = p.seg_lo[i]; segs.hi[i] = p.seg_hi[i]; }
-#define MI355_LIGHT_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, p.counters, chunk, (int32_t)p.window_elems, hint, segs, (val_t)p.alpha, (val_t)p.beta
+#define MI355_LIGHT_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, p.counters, cmap, (int32_t)p.window_elems, hint, segs, (val_t)p.alpha, (val_t)p.beta
 #define MI355_LIGHT_CASE(TT)                                                                                   \
     case TT:                                                                                                   \
         if (p.window_elems > 0 && p.n_seg >= 2)                                                                \
-            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, kMaxSegments, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS); \
+            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, kMaxSegments, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS); \
         else if (p.window_elems > 0)                                                                           \
-            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, 1, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
+            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, 1, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
         else                                                                                                   \
-            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, 0, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
+            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, 0, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
         break;
+    if (p.balanced) {   // vector width per chunk (chunk_rows_any); the T of the template is not used
+        if (p.window_elems > 0)
+            hipLaunchKernelGGL((light_rows_window_kernel<2, R, 1, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);
+        else
+            hipLaunchKernelGGL((light_rows_window_kernel<2, R, 0, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);
+        MI355_HIP_TRY(hipGetLastError());
+        return MI355_SPMV_OK;
+    }
     switch (p.lanes_per_row) {
         MI355_LIGHT_CASE(2)
         MI355_LIGHT_CASE(4)

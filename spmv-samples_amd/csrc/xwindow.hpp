@@ -235,6 +235,27 @@ __device__ __forceinline__ val_t window_gather(const XWindow<val_t>& win, const 
 //   [ window_elems values of x ][ rows+1 row bounds (off_t) ][ rows results (val_t) ][ rows/32 flag words ]
 constexpr int kMaxChunkRows = 2048;   // upper bound of rows per chunk (pick_rows_per_chunk)
 constexpr int kLongSteps = 16;        // a row is "long" beyond this many steps of its T-lane vector
+constexpr int kHugeRow = 1024;        // a long row beyond this many nonzeros is summed by the whole workgroup
+
+// How chunk ids map to rows.  Uniform plans: chunk c = rows [c * rows_per_chunk, ...).  nnz-balanced plans
+// (analyze.hip, decide_balance): boundaries from a table built at plan creation, so that a chunk of a
+// power-law matrix holds a bounded number of nonzeros as well as of rows.
+struct ChunkMap {
+    const int32_t* table;     // n_chunks + 1 boundaries, or nullptr
+    int32_t rows_per_chunk;   // uniform plans
+    int32_t rows_cap;         // rows the workgroup's LDS layout holds
+    int64_t n_chunks;
+    int32_t long_steps;       // a row is "long" (left to the second pass) beyond this many steps of its vector
+    __device__ __forceinline__ void range(int64_t c, int32_t n_rows, int64_t& rb, int64_t& re) const {
+        if (table) {
+            rb = table[c];
+            re = table[c + 1];
+        } else {
+            rb = c * rows_per_chunk;
+            re = min(rb + rows_per_chunk, int64_t(n_rows));
+        }
+    }
+};
 
 __host__ __device__ inline size_t lds_align16(size_t v) { return (v + 15) & ~size_t(15); }
 __host__ __device__ inline size_t chunk_lds_bytes(int window_elems, int rows, size_t off_bytes, size_t val_bytes) {
@@ -249,6 +270,7 @@ struct ChunkScratch {
     val_t* s_y;           // rows     : results of the chunk, stored to y in one coalesced sweep
     unsigned* long_map;   // rows / 32 + 1 : one bit per row, set = long row, summed in the second pass
     val_t alpha, beta;    // y = alpha * (A x) + beta * y   (1, 0 unless mi355_spmv_plan_set_alpha_beta)
+    int long_steps = kLongSteps;
     __device__ ChunkScratch(unsigned char* base, int window_elems, int rows) {
         s_x = reinterpret_cast<val_t*>(base);
         base += lds_align16(size_t(window_elems) * sizeof(val_t));
@@ -321,7 +343,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     using v4 = typename Vec4<val_t>::type;
     constexpr int VECS = kBlock / T;
     constexpr int STRIDE = VECS * R;                       // rows per group
-    constexpr off_t LONG = off_t(T) * 4 * kLongSteps;
+    const off_t LONG = off_t(T) * 4 * scr.long_steps;
     const int lane = threadIdx.x & (T - 1);
     const int vec = threadIdx.x / T;
     const int rows = int(chunk_end - chunk_begin);
@@ -457,14 +479,19 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     const int wave = threadIdx.x / kWave;
     const int words = (rows + 31) >> 5;
     int turn = 0;                                   // marked rows are dealt to the waves in turn
+    bool any_huge = false;                          // same in every thread: it depends on LDS contents only
     for (int w = 0; w < words; ++w) {
         unsigned bits = scr.long_map[w];            // same value in every lane
         while (bits) {
             const int bpos = __ffs(bits) - 1;
             bits &= bits - 1;
-            if ((turn++ & (kBlock / kWave - 1)) != wave) continue;   // wave-uniform
             const int local = (w << 5) + bpos;
             const off_t start = scr.s_b[local], end = scr.s_b[local + 1];
+            if (end - start > off_t(kHugeRow)) {                     // left to the whole workgroup, below
+                any_huge = true;
+                continue;
+            }
+            if ((turn++ & (kBlock / kWave - 1)) != wave) continue;   // wave-uniform
             val_t sum = val_t(0);
             for (off_t j = (start & ~off_t(3)) + off_t(lane64) * 4; j < end; j += off_t(kWave) * 8) {
                 int4v c0, c1;
@@ -478,6 +505,69 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
             }
             sum = vector_reduce<kWave, val_t>(sum);
             if (lane64 == 0) scr.s_y[local] = sum;
+        }
+    }
+
+    // ... and a hub row (more than kHugeRow nonzeros: one wave would need many dependent steps) by all four
+    // waves, partial sums folded through LDS in wave order
+    if (any_huge) {
+        __shared__ val_t s_part[kBlock / kWave];
+        for (int w = 0; w < words; ++w) {
+            unsigned bits = scr.long_map[w];
+            while (bits) {
+                const int bpos = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const int local = (w << 5) + bpos;
+                const off_t start = scr.s_b[local], end = scr.s_b[local + 1];
+                if (end - start <= off_t(kHugeRow)) continue;            // uniform over the workgroup
+                // the main loop's pipeline again: R slabs of kBlock x 4 nonzeros per lane in flight, the next
+                // R issued before the current ones are consumed, branch-free clamped addresses (a slab past
+                // the row re-reads the row's first line and is masked by hi_v)
+                val_t sum = val_t(0);
+                constexpr int64_t SLAB = int64_t(kBlock) * 4;                    // (64-bit: may step past 2^31)
+                const off_t hi_v = end < nnz_vec ? end : nnz_vec;
+                const off_t first = start & ~off_t(3);
+                struct Slabs { int4v c[R]; v4 a[R]; };
+                auto issue_slabs = [&](int64_t it, Slabs& S) {
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        const int64_t j = it + u * SLAB + int64_t(threadIdx.x) * 4;
+                        off_t jl = j < int64_t(hi_v) ? off_t(j) : first;
+                        jl = jl < j_max ? jl : j_max;
+                        S.c[u] = stream_load(reinterpret_cast<const int4v*>(Aj + jl));
+                        S.a[u] = stream_load(reinterpret_cast<const v4*>(Ax + jl));
+                    }
+                };
+                auto eat_slabs = [&](int64_t it, const Slabs& S) {
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        const int64_t j = it + u * SLAB + int64_t(threadIdx.x) * 4;
+                        accumulate(sum, S.c[u], S.a[u], j < int64_t(hi_v) ? off_t(j) : hi_v, start, hi_v);
+                    }
+                };
+                {
+                    Slabs S0, S1;
+                    issue_slabs(first, S0);
+                    for (int64_t it = first; it < int64_t(hi_v); it += 2 * R * SLAB) {   // uniform over the workgroup
+                        issue_slabs(it + R * SLAB, S1);
+                        eat_slabs(it, S0);
+                        issue_slabs(it + 2 * R * SLAB, S0);
+                        eat_slabs(it + R * SLAB, S1);
+                    }
+                }
+                if (threadIdx.x == 0 && end > nnz_vec)                           // the arrays' last, partial group
+                    for (off_t k = (start > nnz_vec ? start : nnz_vec); k < end; ++k) sum += Ax[k] * x[Aj[k]];
+                sum = vector_reduce<kWave, val_t>(sum);
+                if (lane64 == 0) s_part[wave] = sum;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    val_t total = s_part[0];
+#pragma unroll
+                    for (int i = 1; i < kBlock / kWave; ++i) total += s_part[i];
+                    scr.s_y[local] = total;
+                }
+                __syncthreads();
+            }
         }
     }
 
@@ -503,6 +593,27 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
             if (beta != val_t(0)) v += beta * yc[i];
             yc[i] = v;
         }
+    }
+}
+
+// chunk_rows with the vector width chosen PER CHUNK (nnz-balanced plans): a power-law matrix has chunks of
+// 2 000 near-empty rows and chunks of 100 rows x 120 nonzeros; one width for all of them leaves the second
+// kind walking 16 dependent steps per row.  Three widths (2, 8, 32 lanes: rows of <= 8, 32, 128 nonzeros in
+// one step) from the chunk's own mean row length, read from the bounds already in LDS.
+template <int T, int R, bool WINDOW, bool ADAPT, typename off_t, typename val_t, typename Win>
+__device__ __forceinline__ void chunk_rows_any(int64_t chunk_begin, int64_t chunk_end, off_t nnz,
+                                               const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
+                                               const val_t* __restrict__ Ax, const val_t* __restrict__ x,
+                                               val_t* __restrict__ y, const Win& win,
+                                               const ChunkScratch<off_t, val_t>& scr) {
+    if constexpr (!ADAPT) {
+        chunk_rows<T, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+    } else {
+        const int rows = int(chunk_end - chunk_begin);
+        const off_t mean = (scr.s_b[rows] - scr.s_b[0]) / off_t(rows > 0 ? rows : 1);   // uniform over the workgroup
+        if (mean <= 16) chunk_rows<2, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+        else if (mean <= 64) chunk_rows<8, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+        else chunk_rows<32, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
     }
 }
 

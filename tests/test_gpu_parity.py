@@ -269,6 +269,44 @@ def test_execute_is_capturable_in_a_hip_graph(sp, oracle, kind):
     p.destroy()
 
 
+def test_chunks_are_cut_by_weight_only_when_rows_are_uneven(sp, oracle):
+    """decide_balance (analyze.hip): equal-row chunks for uniform matrices (no table), weight-cut
+    chunks when the heaviest equal-row chunk is more than twice the mean.  Either way every row is
+    computed exactly once (integer-valued data: bit-exact), hub rows (summed by a whole workgroup) included."""
+    rng = np.random.RandomState(41)
+    n, n_cols = 60000, 5000
+    lens = rng.randint(0, 6, size=n).astype(np.int64)
+    lens[:300] = rng.randint(200, 1200, size=300)        # the heavy head of a power-law matrix
+    lens[7] = 9000                                       # hub rows: whole-workgroup pass
+    lens[40000] = 20000
+    Ap = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=Ap[1:])
+    nnz = int(Ap[-1])
+    Aj = rng.randint(0, n_cols, size=nnz).astype(np.int32)
+    Ax = rng.randint(-3, 4, size=nnz).astype(np.float32)
+    x = rng.randint(-2, 3, size=n_cols).astype(np.float32)
+    want = oracle.spmv_serial(Ap.astype(np.int32), Aj, Ax, x)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    for off in (np.int32, np.int64):
+        dAp, dAj, dAx, dx = d(Ap.astype(off)), d(Aj), d(Ax), d(x)
+        for kind in ("vector", "light"):
+            p = sp.Plan(kind, n, n_cols, nnz, dAp, dAj, torch.float32)
+            info = p.info()
+            if os.environ.get("MI355_SPMV_BALANCE") != "0":
+                assert info["balanced_chunks"] == 1 and info["n_chunks"] >= 1
+            y = torch.full((n,), float("nan"), device=DEV)
+            p.execute(dAx, dx, y)
+            torch.cuda.synchronize()
+            assert np.array_equal(y.cpu().numpy(), want), (kind, off)
+            p.destroy()
+    # a uniform matrix keeps equal-row chunks
+    Ap2, Aj2, Ax2 = random_csr(rng, 60000, 5000, 12)
+    p = sp.Plan("vector", 60000, 5000, int(Ap2[-1]), d(Ap2), d(Aj2), torch.float32)
+    if "MI355_SPMV_BALANCE" not in os.environ:      # (scripts/gpu_env_matrix.sh forces either plan)
+        assert p.info()["balanced_chunks"] == 0
+    p.destroy()
+
+
 # ---- BASELINE-sized inputs ---------------------------------------------------------------------
 
 @pytest.mark.parametrize("kind", KINDS)
