@@ -262,13 +262,13 @@ static int64_t cluster_bands(Plan& p, int64_t rows) {
     return need;
 }
 
-// Window size (elements) for a workgroup that owns `rows_per_workgroup` consecutive
-// rows: the full 36 KB when the sampled band plus those rows fits within 1.5x of
-// it (the kernels centre a too-small window on the span), else none.
-// MI355_SPMV_WINDOW=0|1 forces the choice (tuning / tests).
+// Window size (elements) for a workgroup that owns `rows_per_workgroup` consecutive rows: what the
+// sampled band plus those rows needs, up to the plan's LDS budget (p.window_bytes), when that is within
+// 1.5x of the budget (the kernels centre a too-small window on the span); else several narrow bands; else
+// none.  MI355_SPMV_WINDOW=0|1 forces the choice (tuning / tests).
 int pick_window_elems(Plan& p, int64_t rows_per_workgroup) {
     const int val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
-    const int cap = kWindowBytes / val_bytes;
+    const int cap = (p.window_bytes > 0 ? p.window_bytes : kWindowBytes) / val_bytes;
     p.window_from_band = false;
     const char* force = getenv("MI355_SPMV_WINDOW");
     if (force) return atoi(force) ? cap : 0;
@@ -278,7 +278,12 @@ int pick_window_elems(Plan& p, int64_t rows_per_workgroup) {
     const char* band = getenv("MI355_SPMV_WINDOW_FROM_BAND");
     p.window_from_band = band ? atoi(band) != 0 : span <= int64_t(cap) * 9 / 8;
     p.n_seg = 0;
-    if (span <= int64_t(cap) * 3 / 2) return cap;
+    if (span <= int64_t(cap) * 3 / 2) {
+        // LDS is occupancy: take what the span needs (a sampled window is widened by an eighth + 64 per side)
+        const int64_t want = p.window_from_band ? span + 8 : span + 2 * (span / 8 + 64) + 8;
+        const int64_t elems = (std::min<int64_t>(want, cap) + 3) & ~int64_t(3);
+        return int(std::min<int64_t>(elems, cap));
+    }
     // one window cannot hold the band: do a few narrow ones?  (MI355_SPMV_SEGMENTS=0 disables)
     const char* seg = getenv("MI355_SPMV_SEGMENTS");
     if (!(seg && atoi(seg) == 0)) {
@@ -289,6 +294,52 @@ int pick_window_elems(Plan& p, int64_t rows_per_workgroup) {
     }
     p.n_seg = 0;
     return 0;
+}
+
+// LDS a workgroup may take: 3 workgroups of 256 threads per CU (what the 36 KB window was sized for),
+// or 2 of 512 threads (up to 64 KB each, ~1 KB of it static).
+static int window_budget(const Plan& p, int block_threads, int64_t rows) {
+    if (block_threads == kBlock) return kWindowBytes;
+    const size_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
+    const int64_t avail = 63 * 1024 - int64_t(chunk_lds_bytes(0, int(rows), off_bytes, val_bytes));   // <= 64 KB per launch
+    return int(avail < 0 ? 0 : avail);
+}
+
+// VECTOR / LIGHT: workgroup size, rows per chunk and the window of x.  R = rows a vector keeps in flight,
+// div = the kind's chunk divisor (LIGHT's tuning knob).
+// Workgroup size: 512 threads own a chunk twice as long (64 K nonzeros) — the window of x is staged half as
+// often per row and 2 x 8 waves sit on a CU instead of 3 x 4 (LDS-bound either way): 190 -> 178 us on the
+// S32-band target.  VECTOR only (allow_wide): the persistent LIGHT grid lost with it (199 -> 237 us).
+void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
+    auto shape = [&](int block_threads, int64_t nnz_per_chunk) {
+        p.block_threads = block_threads;
+        const int64_t pass = int64_t(block_threads / p.lanes_per_row) * R;
+        int64_t rows = pick_rows_per_chunk(p.nnz, p.n_rows, p.lanes_per_row, R, block_threads, nnz_per_chunk);
+        if (div > 1) rows = (rows / div + pass - 1) / pass * pass;
+        if (const char* e = getenv("MI355_SPMV_ROWS_PER_CHUNK")) {
+            int64_t r = atoll(e);
+            r = (r + pass - 1) / pass * pass;
+            if (r >= pass && r <= kMaxChunkRows) rows = r;
+        }
+        if (rows < pass) rows = pass;
+        p.rows_per_chunk = rows;
+        p.window_bytes = window_budget(p, block_threads, rows);
+        p.window_elems = pick_window_elems(p, rows);
+        if (const int64_t fit = segment_rows_fit(p)) {   // several bands: shrink the chunk until they all fit
+            if (fit < p.rows_per_chunk && fit >= pass) p.rows_per_chunk = fit / pass * pass;
+        }
+    };
+    const char* force = getenv("MI355_SPMV_BLOCK");
+    if (force ? atoi(force) == kWideBlock : allow_wide) {
+        shape(kWideBlock, 65536);
+        const int64_t mean = p.n_rows > 0 ? (p.nnz + p.n_rows - 1) / p.n_rows : 1;
+        // keep it when (a) the ">= 4 chunks per CU" rule left the chunk long and (b) one window placed from the
+        // band serves it (with 64-bit offsets / fp64 / several bands the 64 KB a launch may take is better spent
+        // on three workgroups of 256: C4 stand-in 660 us vs 824 us)
+        const bool long_chunk = p.rows_per_chunk * mean >= 49152 || p.rows_per_chunk >= kMaxChunkRows;
+        if (force || (long_chunk && p.window_elems > 0 && p.n_seg < 2 && p.window_from_band)) return;
+    }
+    shape(kBlock, 32768);
 }
 
 // Rows per workgroup for which the plan's bands fit the window exactly:

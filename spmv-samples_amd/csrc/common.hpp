@@ -13,6 +13,7 @@ namespace mi355 {
 
 constexpr int kWave = 64;            // gfx950 wavefront width
 constexpr int kBlock = 256;          // 4 waves per workgroup
+constexpr int kWideBlock = 512;      // VECTOR / LIGHT on big uniform matrices: 8 waves, chunks twice as long
 constexpr int kXcds = 8;             // XCDs per MI355X, each with a private L2
 constexpr int kCus = 256;            // compute units per MI355X
 
@@ -59,6 +60,8 @@ struct Plan {
     // structure probe (plan creation): band of (column - row) seen on sampled rows
     int64_t band_lo, band_hi;   // valid when probe_ok
     bool probe_ok;
+    int block_threads;          // VECTOR / LIGHT: 256, or 512 for big uniform matrices (chunks twice as long)
+    int window_bytes;           // LDS budget of the x window per workgroup (pick_window_elems)
     int window_elems;           // LDS window of x per workgroup, in elements; 0 = no window
     bool window_from_band;      // place the window from band_lo/band_hi instead of sampling per chunk
     // multi-band plan: up to 4 bands of (column - row) found by clustering the probe's samples
@@ -96,6 +99,7 @@ int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x
 int probe_structure(Plan& p);
 int pick_window_elems(Plan& p, int64_t rows_per_workgroup);
 int64_t segment_rows_fit(const Plan& p);
+void shape_chunks(Plan& p, int rows_in_flight, int64_t chunk_div, bool allow_wide);   // VECTOR / LIGHT: block size, chunk, window
 int long_steps_for(const Plan& p);   // steps of its vector after which a row is left to the long-row pass
 int decide_balance(Plan& p);       // VECTOR / LIGHT, after shape_*: uniform or nnz-balanced chunks
 int build_chunk_table(Plan& p);    // after the scratch is allocated

@@ -22,14 +22,14 @@
 
 namespace mi355 {
 
-template <int T, int R, int NSEG, bool ADAPT, typename off_t, typename val_t>
-__global__ __launch_bounds__(kBlock) void csr_vector_window_kernel(
+template <int BLOCK, int T, int R, int NSEG, bool ADAPT, typename off_t, typename val_t>
+__global__ __launch_bounds__(BLOCK) void csr_vector_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, ChunkMap cmap,
     int32_t window_cap, BandHint hint, SegmentPlan segs, val_t alpha, val_t beta) {
     // NSEG: 0 = no window (plain gathers), 1 = one window of x in LDS, kMaxSegments = several bands
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
-    __shared__ int s_red[2 * (kBlock / kWave)];
+    __shared__ int s_red[2];
     ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, cmap.rows_cap);
     scr.alpha = alpha;
     scr.beta = beta;
@@ -41,11 +41,11 @@ __global__ __launch_bounds__(kBlock) void csr_vector_window_kernel(
     stage_chunk_bounds<off_t, val_t>(scr, rb, re, Ap);      // ordered before chunk_rows by the barrier below
     if constexpr (NSEG > 1) {
         const XWindowN<val_t> win = stage_x_segments<val_t>(rb, re, n_cols, x, scr.s_x, window_cap, segs);
-        chunk_rows_any<T, R, true, ADAPT, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
+        chunk_rows_any<BLOCK, T, R, true, ADAPT, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
     } else {
         const XWindow<val_t> win =
             stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
-        chunk_rows_any<T, R, NSEG == 1, ADAPT, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
+        chunk_rows_any<BLOCK, T, R, NSEG == 1, ADAPT, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
     }
 }
 
@@ -75,29 +75,14 @@ template <typename val_t> constexpr int rows_in_flight() { return sizeof(val_t) 
 void shape_vector(Plan& p) {
     p.lanes_per_row = pick_lanes_per_row(p.nnz, p.n_rows, p.elems_per_lane);
     const int R = p.val_type == MI355_VAL_F64 ? rows_in_flight<double>() : rows_in_flight<float>();
-    if (const char* e = getenv("MI355_SPMV_LANES")) {          // tuning knobs
+    if (const char* e = getenv("MI355_SPMV_LANES")) {          // tuning knob
         const int t = atoi(e);
         if (t == 2 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64) p.lanes_per_row = t;
     }
-    p.rows_per_chunk = pick_rows_per_chunk(p.nnz, p.n_rows, p.lanes_per_row, R);
-    if (const char* e = getenv("MI355_SPMV_ROWS_PER_CHUNK")) {
-        const int64_t pass = int64_t(kBlock / p.lanes_per_row) * R;
-        int64_t r = atoll(e);
-        r = (r + pass - 1) / pass * pass;
-        if (r >= pass && r <= kMaxChunkRows) p.rows_per_chunk = r;
-    }
+    shape_chunks(p, R, 1, true);     // workgroup size, rows per chunk, window of x (analyze.hip)
     p.grid_blocks = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
     if (p.grid_blocks < 1) p.grid_blocks = 1;
     p.n_tiles = p.grid_blocks;
-    p.window_elems = pick_window_elems(p, p.rows_per_chunk);
-    if (const int64_t fit = segment_rows_fit(p)) {   // several bands: shrink the chunk until they all fit
-        const int64_t pass = int64_t(kBlock / p.lanes_per_row) * R;
-        if (fit < p.rows_per_chunk && fit >= pass) {
-            p.rows_per_chunk = fit / pass * pass;
-            p.grid_blocks = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
-            p.n_tiles = p.grid_blocks;
-        }
-    }
     p.n_kernels = 1;
     snprintf(p.main_kernel, sizeof(p.main_kernel), "csr_vector_window_kernel");
 }
@@ -105,18 +90,20 @@ void shape_vector(Plan& p) {
 // after decide_balance: one workgroup per chunk, window sized for the rows a chunk may hold
 void reshape_vector_balanced(Plan& p) {
     if (!p.balanced) return;
+    p.block_threads = kBlock;          // (weight-cut chunks are sized for 256 threads)
+    p.window_bytes = kWindowBytes;
     p.grid_blocks = p.n_chunks;
     p.n_tiles = p.n_chunks;
     p.window_elems = pick_window_elems(p, p.rows_cap);
     if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }   // (the multi-band plan is sized for uniform chunks)
 }
 
-template <typename off_t, typename val_t>
+template <int BLOCK, typename off_t, typename val_t>
 static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
                                 hipStream_t s) {
     constexpr int R = rows_in_flight<val_t>();
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
-    const dim3 grid((unsigned)p.grid_blocks), block(kBlock);
+    const dim3 grid((unsigned)p.grid_blocks), block(BLOCK);
     const off_t nnz = (off_t)p.nnz;
     const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(off_t), sizeof(val_t));
     const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, long_steps_for(p)};
@@ -127,17 +114,17 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
 #define MI355_VEC_CASE(TT)                                                                                   \
     case TT:                                                                                                 \
         if (p.window_elems > 0 && p.n_seg >= 2)                                                              \
-            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, kMaxSegments, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS); \
+            hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, R, kMaxSegments, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS); \
         else if (p.window_elems > 0)                                                                         \
-            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, 1, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
+            hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, R, 1, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
         else                                                                                                 \
-            hipLaunchKernelGGL((csr_vector_window_kernel<TT, R, 0, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
+            hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, R, 0, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
         break;
-    if (p.balanced) {   // vector width per chunk (chunk_rows_any); the T of the template is not used
+    if constexpr (BLOCK == kBlock) if (p.balanced) {   // vector width per chunk (chunk_rows_any); the T of the template is not used
         if (p.window_elems > 0)
-            hipLaunchKernelGGL((csr_vector_window_kernel<2, R, 1, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);
+            hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, 2, R, 1, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);
         else
-            hipLaunchKernelGGL((csr_vector_window_kernel<2, R, 0, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);
+            hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, 2, R, 0, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);
         MI355_HIP_TRY(hipGetLastError());
         return MI355_SPMV_OK;
     }
@@ -192,7 +179,9 @@ int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* 
     // that passes an offset view gets the 4-byte-per-lane form instead.
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
-    if (aligned && p.nnz >= 4) return launch_vector_window<off_t, val_t>(p, Ap, Ax, x, y, s);
+    if (aligned && p.nnz >= 4)
+        return p.block_threads == kWideBlock ? launch_vector_window<kWideBlock, off_t, val_t>(p, Ap, Ax, x, y, s)
+                                             : launch_vector_window<kBlock, off_t, val_t>(p, Ap, Ax, x, y, s);
     return launch_vector_plain<off_t, val_t>(p, Ap, Ax, x, y, s);
 }
 

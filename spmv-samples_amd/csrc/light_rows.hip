@@ -82,14 +82,14 @@ __device__ __forceinline__ void light_leave(unsigned long long* __restrict__ cou
     }
 }
 
-template <int T, int R, int NSEG, bool ADAPT, typename off_t, typename val_t>
-__global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
+template <int BLOCK, int T, int R, int NSEG, bool ADAPT, typename off_t, typename val_t>
+__global__ __launch_bounds__(BLOCK) void light_rows_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
     unsigned long long* __restrict__ counters, ChunkMap cmap, int32_t window_cap, BandHint hint,
     SegmentPlan segs, val_t alpha, val_t beta) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
-    __shared__ int s_red[2 * (kBlock / kWave)];
+    __shared__ int s_red[2];
     __shared__ unsigned long long s_got;
     __shared__ unsigned s_busy;
     ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, cmap.rows_cap);
@@ -127,11 +127,11 @@ __global__ __launch_bounds__(kBlock) void light_rows_window_kernel(
             if constexpr (NSEG > 1) {
                 const XWindowN<val_t> win =
                     stage_x_segments<val_t>(chunk_begin, chunk_end, n_cols, x, scr.s_x, window_cap, segs);
-                chunk_rows_any<T, R, true, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+                chunk_rows_any<BLOCK, T, R, true, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
             } else {
                 const XWindow<val_t> win = stage_x_window<off_t, val_t>(
                     chunk_begin, chunk_end, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
-                chunk_rows_any<T, R, NSEG == 1, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+                chunk_rows_any<BLOCK, T, R, NSEG == 1, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
             }
             __syncthreads();  // every wave is done with the window before it is refilled
         }
@@ -186,32 +186,24 @@ __global__ __launch_bounds__(kBlock) void light_rows_kernel(
 
 template <typename val_t> constexpr int light_rows_in_flight() { return sizeof(val_t) == 4 ? 4 : 2; }
 
+static int64_t light_resident(const Plan& p) {
+    // persistent grid: what stays resident — 2 workgroups of 512 threads per CU, or 4 of 256 with the
+    // window of x (5 without: VGPR-bound)
+    const char* er = getenv("MI355_LIGHT_BLOCKS_PER_CU");
+    const int per_cu = er && atoi(er) > 0 ? atoi(er) : p.block_threads == kWideBlock ? 2 : (p.window_elems ? 4 : 5);
+    return int64_t(kCus) * per_cu;
+}
+
 void shape_light(Plan& p) {
     p.lanes_per_row = pick_lanes_per_row(p.nnz, p.n_rows, p.elems_per_lane);
     const int R = p.val_type == MI355_VAL_F64 ? light_rows_in_flight<double>() : light_rows_in_flight<float>();
-    const int64_t pass = int64_t(kBlock / p.lanes_per_row) * R;
     const char* ev = getenv("MI355_LIGHT_CHUNK_DIV");
-    const int64_t env_div = ev && atoi(ev) > 0 ? atoi(ev) : 1;
     // chunks: the static kind's size (halving them cost 6 % on the S32-band target: the
     // window of x is staged per chunk), never below one pass of the workgroup
-    int64_t chunk = pick_rows_per_chunk(p.nnz, p.n_rows, p.lanes_per_row, R) / env_div;
-    chunk = (chunk + pass - 1) / pass * pass;
-    if (chunk < pass) chunk = pass;
-    p.rows_per_chunk = chunk;
-    p.n_tiles = (int64_t(p.n_rows) + chunk - 1) / chunk;
-    p.window_elems = pick_window_elems(p, chunk);
-    if (const int64_t fit = segment_rows_fit(p)) {   // several bands: shrink the chunk until they all fit
-        if (fit < chunk && fit >= pass) {
-            chunk = fit / pass * pass;
-            p.rows_per_chunk = chunk;
-            p.n_tiles = (int64_t(p.n_rows) + chunk - 1) / chunk;
-        }
-    }
-    // persistent grid: 4 workgroups per CU with the 36 KB window, 5 without (VGPR-bound),
-    // fewer for small inputs
-    int64_t blocks = p.n_tiles;
-    const char* er = getenv("MI355_LIGHT_BLOCKS_PER_CU");
-    const int64_t resident = int64_t(kCus) * (er && atoi(er) > 0 ? atoi(er) : (p.window_elems ? 4 : 5));
+    shape_chunks(p, R, ev && atoi(ev) > 0 ? atoi(ev) : 1, false);
+    p.n_tiles = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    int64_t blocks = p.n_tiles;                     // fewer than resident for small inputs
+    const int64_t resident = light_resident(p);
     if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
     p.grid_blocks = blocks;
@@ -223,20 +215,21 @@ void shape_light(Plan& p) {
 void reshape_light_balanced(Plan& p) {
     if (!p.balanced) return;
     p.n_tiles = p.n_chunks;
+    p.block_threads = kBlock;          // (weight-cut chunks are sized for 256 threads)
+    p.window_bytes = kWindowBytes;
     p.window_elems = pick_window_elems(p, p.rows_cap);
     if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }
-    const char* er = getenv("MI355_LIGHT_BLOCKS_PER_CU");
-    const int64_t resident = int64_t(kCus) * (er && atoi(er) > 0 ? atoi(er) : (p.window_elems ? 4 : 5));
+    const int64_t resident = light_resident(p);
     p.grid_blocks = p.n_chunks < resident ? p.n_chunks : resident;
     if (p.grid_blocks < 1) p.grid_blocks = 1;
 }
 
-template <typename off_t, typename val_t>
+template <int BLOCK, typename off_t, typename val_t>
 static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
                                hipStream_t s) {
     constexpr int R = light_rows_in_flight<val_t>();
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
-    const dim3 grid((unsigned)p.grid_blocks), block(kBlock);
+    const dim3 grid((unsigned)p.grid_blocks), block(BLOCK);
     const off_t nnz = (off_t)p.nnz;
     const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, long_steps_for(p)};
     const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(off_t), sizeof(val_t));
@@ -247,17 +240,17 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
 #define MI355_LIGHT_CASE(TT)                                                                                   \
     case TT:                                                                                                   \
         if (p.window_elems > 0 && p.n_seg >= 2)                                                                \
-            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, kMaxSegments, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS); \
+            hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, TT, R, kMaxSegments, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS); \
         else if (p.window_elems > 0)                                                                           \
-            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, 1, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
+            hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, TT, R, 1, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
         else                                                                                                   \
-            hipLaunchKernelGGL((light_rows_window_kernel<TT, R, 0, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
+            hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, TT, R, 0, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
         break;
-    if (p.balanced) {   // vector width per chunk (chunk_rows_any); the T of the template is not used
+    if constexpr (BLOCK == kBlock) if (p.balanced) {   // vector width per chunk (chunk_rows_any); the T of the template is not used
         if (p.window_elems > 0)
-            hipLaunchKernelGGL((light_rows_window_kernel<2, R, 1, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);
+            hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, 2, R, 1, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);
         else
-            hipLaunchKernelGGL((light_rows_window_kernel<2, R, 0, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);
+            hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, 2, R, 0, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);
         MI355_HIP_TRY(hipGetLastError());
         return MI355_SPMV_OK;
     }
@@ -309,7 +302,9 @@ int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x
     if (p.n_rows == 0) return MI355_SPMV_OK;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
-    if (aligned && p.nnz >= 4) return launch_light_window<off_t, val_t>(p, Ap, Ax, x, y, s);
+    if (aligned && p.nnz >= 4)
+        return p.block_threads == kWideBlock ? launch_light_window<kWideBlock, off_t, val_t>(p, Ap, Ax, x, y, s)
+                                             : launch_light_window<kBlock, off_t, val_t>(p, Ap, Ax, x, y, s);
     return launch_light_plain<off_t, val_t>(p, Ap, Ax, x, y, s);
 }
 

@@ -84,8 +84,8 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 
 // Workgroup-wide: sample the column range of rows [rb, re), copy that window of x
-// into s_x (capacity `cap` elements).  All kBlock threads must call; ends with a
-// barrier.  s_red: 2 * (kBlock / kWave) ints of LDS scratch.
+// into s_x (capacity `cap` elements).  All threads of the workgroup must call (any size); ends
+// with a barrier.  s_red: 2 ints of LDS scratch.
 // BandHint: the band [lo, hi] of (column - row) the plan's probe saw (analyze.hip).  When the
 // whole band of a chunk fits the window (use == true) the window is placed from it and
 // the per-chunk sample — two dependent loads and a barrier — is skipped.
@@ -159,7 +159,7 @@ __device__ __forceinline__ XWindow<val_t> stage_x_window(int64_t rb, int64_t re,
         __syncthreads();
         return win;
     }
-    int len = hint.use ? span : span + 2 * (span / 8 + 64);
+    int len = hint.use ? span + (PER16 - 1) : span + 2 * (span / 8 + 64);   // (+: the start is rounded down to 16 bytes)
     if (len > cap) len = cap;
     if (len > n_cols) len = n_cols;
     int64_t start = (int64_t(lo) + hi + 1 - len) / 2;
@@ -172,10 +172,11 @@ __device__ __forceinline__ XWindow<val_t> stage_x_window(int64_t rb, int64_t re,
     using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
     int full = (min(lo + len, n_cols & ~(PER16 - 1)) - lo) / PER16;   // whole 16-byte groups inside x
     if (full < 0) full = 0;
-    for (int g = tid; g < full; g += kBlock) {
+    const int nthreads = int(blockDim.x);
+    for (int g = tid; g < full; g += nthreads) {
         *reinterpret_cast<v16*>(s_x + g * PER16) = *reinterpret_cast<const v16*>(x + lo + g * PER16);
     }
-    for (int i = full * PER16 + tid; i < len; i += kBlock) s_x[i] = x[lo + i];
+    for (int i = full * PER16 + tid; i < len; i += nthreads) s_x[i] = x[lo + i];
     __syncthreads();
     return win;
 }
@@ -210,9 +211,9 @@ __device__ __forceinline__ XWindowN<val_t> stage_x_segments(int64_t rb, int64_t 
         win.off[s] = off;
         int full = (min(lo + len, n_cols & ~(PER16 - 1)) - lo) / PER16;   // whole 16-byte groups inside x
         if (full < 0) full = 0;
-        for (int g = tid; g < full; g += kBlock)
+        for (int g = tid; g < full; g += int(blockDim.x))
             *reinterpret_cast<v16*>(s_x + off + g * PER16) = *reinterpret_cast<const v16*>(x + lo + g * PER16);
-        for (int i = full * PER16 + tid; i < len; i += kBlock) s_x[off + i] = x[lo + i];
+        for (int i = full * PER16 + tid; i < len; i += int(blockDim.x)) s_x[off + i] = x[lo + i];
         off += (len + PER16 - 1) & ~(PER16 - 1);
     }
     __syncthreads();
@@ -290,8 +291,8 @@ template <typename off_t, typename val_t>
 __device__ __forceinline__ void stage_chunk_bounds(const ChunkScratch<off_t, val_t>& scr, int64_t chunk_begin,
                                                    int64_t chunk_end, const off_t* __restrict__ Ap) {
     const int rows = int(chunk_end - chunk_begin);
-    for (int i = threadIdx.x; i <= rows; i += kBlock) scr.s_b[i] = Ap[chunk_begin + i];
-    for (int i = threadIdx.x; i < rows / 32 + 1; i += kBlock) scr.long_map[i] = 0u;
+    for (int i = threadIdx.x; i <= rows; i += int(blockDim.x)) scr.s_b[i] = Ap[chunk_begin + i];
+    for (int i = threadIdx.x; i < rows / 32 + 1; i += int(blockDim.x)) scr.long_map[i] = 0u;
 }
 
 // One step of 4 nonzeros of one lane: Aj/Ax group at j (16-byte aligned element index).
@@ -332,16 +333,17 @@ __device__ __forceinline__ void load_group(off_t j, off_t nnz, const int32_t* __
 //    would serialise the chunk behind one vector — the weakness of the reference's
 //    CSR-vector and LightSpMV kernels): its bit is set in an LDS bitmap and a second pass
 //    sums every marked row with a whole 64-lane wave, the four waves taking rows in turn.
-// All kBlock threads must call (wave-wide shuffles and barriers inside); the caller has
-// run stage_chunk_bounds + a barrier.
-template <int T, int R, bool WINDOW, typename off_t, typename val_t, typename Win>
+// All BLOCK threads of the workgroup must call (wave-wide shuffles and barriers inside); the caller
+// has run stage_chunk_bounds + a barrier.
+template <int BLOCK, int T, int R, bool WINDOW, typename off_t, typename val_t, typename Win>
 __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_end, off_t nnz,
                                            const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
                                            const val_t* __restrict__ Ax, const val_t* __restrict__ x,
                                            val_t* __restrict__ y, const Win& win,
                                            const ChunkScratch<off_t, val_t>& scr) {
     using v4 = typename Vec4<val_t>::type;
-    constexpr int VECS = kBlock / T;
+    constexpr int VECS = BLOCK / T;
+    constexpr int WAVES = BLOCK / kWave;
     constexpr int STRIDE = VECS * R;                       // rows per group
     const off_t LONG = off_t(T) * 4 * scr.long_steps;
     const int lane = threadIdx.x & (T - 1);
@@ -491,7 +493,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
                 any_huge = true;
                 continue;
             }
-            if ((turn++ & (kBlock / kWave - 1)) != wave) continue;   // wave-uniform
+            if ((turn++ & (WAVES - 1)) != wave) continue;   // wave-uniform
             val_t sum = val_t(0);
             for (off_t j = (start & ~off_t(3)) + off_t(lane64) * 4; j < end; j += off_t(kWave) * 8) {
                 int4v c0, c1;
@@ -511,7 +513,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     // ... and a hub row (more than kHugeRow nonzeros: one wave would need many dependent steps) by all four
     // waves, partial sums folded through LDS in wave order
     if (any_huge) {
-        __shared__ val_t s_part[kBlock / kWave];
+        __shared__ val_t s_part[WAVES];
         for (int w = 0; w < words; ++w) {
             unsigned bits = scr.long_map[w];
             while (bits) {
@@ -520,11 +522,11 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
                 const int local = (w << 5) + bpos;
                 const off_t start = scr.s_b[local], end = scr.s_b[local + 1];
                 if (end - start <= off_t(kHugeRow)) continue;            // uniform over the workgroup
-                // the main loop's pipeline again: R slabs of kBlock x 4 nonzeros per lane in flight, the next
+                // the main loop's pipeline again: R slabs of BLOCK x 4 nonzeros in flight, the next
                 // R issued before the current ones are consumed, branch-free clamped addresses (a slab past
                 // the row re-reads the row's first line and is masked by hi_v)
                 val_t sum = val_t(0);
-                constexpr int64_t SLAB = int64_t(kBlock) * 4;                    // (64-bit: may step past 2^31)
+                constexpr int64_t SLAB = int64_t(BLOCK) * 4;                    // (64-bit: may step past 2^31)
                 const off_t hi_v = end < nnz_vec ? end : nnz_vec;
                 const off_t first = start & ~off_t(3);
                 struct Slabs { int4v c[R]; v4 a[R]; };
@@ -563,7 +565,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
                 if (threadIdx.x == 0) {
                     val_t total = s_part[0];
 #pragma unroll
-                    for (int i = 1; i < kBlock / kWave; ++i) total += s_part[i];
+                    for (int i = 1; i < WAVES; ++i) total += s_part[i];
                     scr.s_y[local] = total;
                 }
                 __syncthreads();
@@ -581,14 +583,14 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     if (!scaled && (reinterpret_cast<uintptr_t>(yc) & 15u) == 0) {
         using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
         const int full = rows / PER16;
-        for (int g = threadIdx.x; g < full; g += kBlock)
+        for (int g = threadIdx.x; g < full; g += BLOCK)
             __builtin_nontemporal_store(*reinterpret_cast<const v16*>(scr.s_y + g * PER16),
                                         reinterpret_cast<v16*>(yc + g * PER16));
-        for (int i = full * PER16 + threadIdx.x; i < rows; i += kBlock) yc[i] = scr.s_y[i];
+        for (int i = full * PER16 + threadIdx.x; i < rows; i += BLOCK) yc[i] = scr.s_y[i];
     } else if (!scaled) {
-        for (int i = threadIdx.x; i < rows; i += kBlock) yc[i] = scr.s_y[i];
+        for (int i = threadIdx.x; i < rows; i += BLOCK) yc[i] = scr.s_y[i];
     } else {
-        for (int i = threadIdx.x; i < rows; i += kBlock) {
+        for (int i = threadIdx.x; i < rows; i += BLOCK) {
             val_t v = alpha * scr.s_y[i];
             if (beta != val_t(0)) v += beta * yc[i];
             yc[i] = v;
@@ -600,29 +602,30 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
 // 2 000 near-empty rows and chunks of 100 rows x 120 nonzeros; one width for all of them leaves the second
 // kind walking 16 dependent steps per row.  Three widths (2, 8, 32 lanes: rows of <= 8, 32, 128 nonzeros in
 // one step) from the chunk's own mean row length, read from the bounds already in LDS.
-template <int T, int R, bool WINDOW, bool ADAPT, typename off_t, typename val_t, typename Win>
+template <int BLOCK, int T, int R, bool WINDOW, bool ADAPT, typename off_t, typename val_t, typename Win>
 __device__ __forceinline__ void chunk_rows_any(int64_t chunk_begin, int64_t chunk_end, off_t nnz,
                                                const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
                                                const val_t* __restrict__ Ax, const val_t* __restrict__ x,
                                                val_t* __restrict__ y, const Win& win,
                                                const ChunkScratch<off_t, val_t>& scr) {
     if constexpr (!ADAPT) {
-        chunk_rows<T, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+        chunk_rows<BLOCK, T, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
     } else {
         const int rows = int(chunk_end - chunk_begin);
         const off_t mean = (scr.s_b[rows] - scr.s_b[0]) / off_t(rows > 0 ? rows : 1);   // uniform over the workgroup
-        if (mean <= 16) chunk_rows<2, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
-        else if (mean <= 64) chunk_rows<8, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
-        else chunk_rows<32, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+        if (mean <= 16) chunk_rows<BLOCK, 2, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+        else if (mean <= 64) chunk_rows<BLOCK, 8, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+        else chunk_rows<BLOCK, 32, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
     }
 }
 
 // Rows per workgroup chunk: ~32 K nonzeros (256 KB of fp32 stream) per chunk, a
 // multiple of the rows one pass of the workgroup covers.
-inline int64_t pick_rows_per_chunk(int64_t nnz, int64_t n_rows, int lanes_per_row, int rows_in_flight) {
-    const int64_t pass = int64_t(kBlock / lanes_per_row) * rows_in_flight;
+inline int64_t pick_rows_per_chunk(int64_t nnz, int64_t n_rows, int lanes_per_row, int rows_in_flight,
+                                   int block_threads = kBlock, int64_t nnz_per_chunk = 32768) {
+    const int64_t pass = int64_t(block_threads / lanes_per_row) * rows_in_flight;
     const int64_t mean = n_rows > 0 ? (nnz + n_rows - 1) / n_rows : 1;
-    int64_t rows = 32768 / (mean > 0 ? mean : 1);
+    int64_t rows = nnz_per_chunk / (mean > 0 ? mean : 1);
     // small matrices: prefer >= 4 chunks per CU over long chunks
     const int64_t fill = (n_rows + int64_t(kCus) * 4 - 1) / (int64_t(kCus) * 4);
     if (rows > fill) rows = fill;
