@@ -72,6 +72,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
 
 template <typename val_t> constexpr int rows_in_flight() { return sizeof(val_t) == 4 ? 4 : 2; }
 
+#ifndef MI355_TU_F64   // the host-side shape functions live in the fp32 translation unit only
 void shape_vector(Plan& p) {
     p.lanes_per_row = pick_lanes_per_row(p.nnz, p.n_rows, p.elems_per_lane);
     const int R = p.val_type == MI355_VAL_F64 ? rows_in_flight<double>() : rows_in_flight<float>();
@@ -97,6 +98,8 @@ void reshape_vector_balanced(Plan& p) {
     p.window_elems = pick_window_elems(p, p.rows_cap);
     if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }   // (the multi-band plan is sized for uniform chunks)
 }
+
+#endif  // MI355_TU_F64
 
 template <int BLOCK, typename off_t, typename val_t>
 static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
@@ -185,9 +188,14 @@ int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* 
     return launch_vector_plain<off_t, val_t>(p, Ap, Ax, x, y, s);
 }
 
+// One translation unit per value type (csr_vector_f64.hip includes this file with MI355_TU_F64): the two
+// halves of the instantiations compile side by side.
+#ifndef MI355_TU_F64
 template int launch_vector<int32_t, float>(const Plan&, const int32_t*, const float*, const float*, float*, hipStream_t);
-template int launch_vector<int32_t, double>(const Plan&, const int32_t*, const double*, const double*, double*, hipStream_t);
 template int launch_vector<int64_t, float>(const Plan&, const int64_t*, const float*, const float*, float*, hipStream_t);
+#else
+template int launch_vector<int32_t, double>(const Plan&, const int32_t*, const double*, const double*, double*, hipStream_t);
 template int launch_vector<int64_t, double>(const Plan&, const int64_t*, const double*, const double*, double*, hipStream_t);
+#endif
 
 }  // namespace mi355

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(kBlock) void light_rows_kernel(
 
 template <typename val_t> constexpr int light_rows_in_flight() { return sizeof(val_t) == 4 ? 4 : 2; }
 
+#ifndef MI355_TU_F64   // the host-side shape functions live in the fp32 translation unit only
 static int64_t light_resident(const Plan& p) {
     // persistent grid: what stays resident — 2 workgroups of 512 threads per CU, or 4 of 256 with the
     // window of x (5 without: VGPR-bound)
@@ -223,6 +224,8 @@ void reshape_light_balanced(Plan& p) {
     p.grid_blocks = p.n_chunks < resident ? p.n_chunks : resident;
     if (p.grid_blocks < 1) p.grid_blocks = 1;
 }
+
+#endif  // MI355_TU_F64
 
 template <int BLOCK, typename off_t, typename val_t>
 static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
@@ -308,9 +311,13 @@ int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x
     return launch_light_plain<off_t, val_t>(p, Ap, Ax, x, y, s);
 }
 
+// One translation unit per value type (light_rows_f64.hip includes this file with MI355_TU_F64).
+#ifndef MI355_TU_F64
 template int launch_light<int32_t, float>(const Plan&, const int32_t*, const float*, const float*, float*, hipStream_t);
-template int launch_light<int32_t, double>(const Plan&, const int32_t*, const double*, const double*, double*, hipStream_t);
 template int launch_light<int64_t, float>(const Plan&, const int64_t*, const float*, const float*, float*, hipStream_t);
+#else
+template int launch_light<int32_t, double>(const Plan&, const int32_t*, const double*, const double*, double*, hipStream_t);
 template int launch_light<int64_t, double>(const Plan&, const int64_t*, const double*, const double*, double*, hipStream_t);
+#endif
 
 }  // namespace mi355
