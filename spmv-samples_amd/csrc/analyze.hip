@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
+#include <mutex>
 #include <new>
 
 #include "common.hpp"
@@ -65,6 +66,28 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(int32_t n_rows, const off
     }
 }
 
+// Device scratch of the plan-time kernels (probe samples, heaviest-chunk word): one allocation per device
+// for the life of the process instead of a hipMalloc + hipFree (an implicit device synchronisation) per plan —
+// the one-shot entry points create a plan per call, like the reference's kinds.  plan_create holds the lock
+// while it uses the buffer.
+constexpr size_t kAnalysisWords = 2 + size_t(kBlock) * kProbePerRow + 2;
+static std::mutex g_analysis_mutex;
+static long long* g_analysis_buf[64] = {};
+
+static long long* analysis_buffer() {   // call with g_analysis_mutex held
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!g_analysis_buf[dev]) {
+        void* ptr = nullptr;
+        if (hipMalloc(&ptr, kAnalysisWords * sizeof(long long)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        g_analysis_buf[dev] = static_cast<long long*>(ptr);
+    }
+    return g_analysis_buf[dev];
+}
+
 int probe_structure(Plan& p) {
     p.probe_ok = false;
     p.band_lo = p.band_hi = 0;
@@ -73,8 +96,9 @@ int probe_structure(Plan& p) {
     if (p.n_rows <= 0 || p.nnz <= 0) return MI355_SPMV_OK;
     constexpr size_t N = 2 + size_t(kBlock) * kProbePerRow;
     static_assert(size_t(kBlock) * kProbePerRow <= sizeof(p.probe_off) / sizeof(p.probe_off[0]), "probe buffer");
-    long long* d_out = nullptr;
-    MI355_HIP_TRY(hipMalloc(&d_out, N * sizeof(long long)));
+    std::lock_guard<std::mutex> lock(g_analysis_mutex);
+    long long* d_out = analysis_buffer();
+    if (!d_out) { set_error("probe_structure: no device scratch"); return MI355_SPMV_ENOMEM; }
     if (p.off_type == MI355_OFF_I32)
         hipLaunchKernelGGL((probe_kernel<int32_t>), dim3(1), dim3(kBlock), 0, nullptr, p.n_rows,
                            static_cast<const int32_t*>(p.Ap), p.Aj, d_out);
@@ -84,7 +108,6 @@ int probe_structure(Plan& p) {
     long long* h = new (std::nothrow) long long[N];
     hipError_t e = h ? hipGetLastError() : hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMemcpy(h, d_out, N * sizeof(long long), hipMemcpyDeviceToHost);   // synchronises
-    (void)hipFree(d_out);
     if (e != hipSuccess) {
         delete[] h;
         set_error("probe_structure: %s", hipGetErrorString(e));
@@ -96,7 +119,7 @@ int probe_structure(Plan& p) {
         p.probe_ok = true;
         for (size_t i = 2; i < N; ++i)
             if (h[i] != LLONG_MAX) p.probe_off[p.probe_n++] = h[i];
-        std::sort(p.probe_off, p.probe_off + p.probe_n);
+        p.probe_sorted = false;    // sorted on first use (cluster_bands): most plans never need the samples
     }
     delete[] h;
     return MI355_SPMV_OK;
@@ -171,9 +194,11 @@ int decide_balance(Plan& p) {
     if (p.n_rows <= 0 || p.nnz <= 0 || (ev && atoi(ev) == 0)) return MI355_SPMV_OK;
     bool want = ev && atoi(ev) != 0;
     if (!want && p.n_chunks >= 2) {
-        unsigned long long* d_max = nullptr;
-        MI355_HIP_TRY(hipMalloc(&d_max, sizeof(unsigned long long)));
-        hipError_t e = hipMemset(d_max, 0, sizeof(unsigned long long));
+        std::lock_guard<std::mutex> lock(g_analysis_mutex);
+        long long* buf = analysis_buffer();
+        if (!buf) { set_error("decide_balance: no device scratch"); return MI355_SPMV_ENOMEM; }
+        unsigned long long* d_max = reinterpret_cast<unsigned long long*>(buf + kAnalysisWords - 1);
+        hipError_t e = hipMemsetAsync(d_max, 0, sizeof(unsigned long long), nullptr);
         const unsigned g = unsigned(std::min<int64_t>((p.n_chunks + kBlock - 1) / kBlock, 1024));
         if (e == hipSuccess) {
             if (p.off_type == MI355_OFF_I32)
@@ -186,7 +211,6 @@ int decide_balance(Plan& p) {
         }
         unsigned long long h_max = 0;
         if (e == hipSuccess) e = hipMemcpy(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost);   // synchronises
-        (void)hipFree(d_max);
         if (e != hipSuccess) {
             set_error("decide_balance: %s", hipGetErrorString(e));
             return MI355_SPMV_EHIP;
@@ -231,6 +255,10 @@ int build_chunk_table(Plan& p) {
 static int64_t cluster_bands(Plan& p, int64_t rows) {
     p.n_seg = 0;
     if (p.probe_n == 0) return 0;
+    if (!p.probe_sorted) {
+        std::sort(p.probe_off, p.probe_off + p.probe_n);
+        p.probe_sorted = true;
+    }
     int64_t lo[64], hi[64];
     int n = 0;
     lo[0] = hi[0] = p.probe_off[0];

@@ -3,9 +3,14 @@
 // in this library: every entry point either launches HIP kernels or fails.
 
 #include <cstdarg>
+#include <mutex>
 #include <new>
 
 #include "common.hpp"
+
+struct mi355_spmv_plan {   // the opaque handle of include/mi355_spmv.h
+    mi355::Plan p;
+};
 
 namespace mi355 {
 
@@ -19,6 +24,38 @@ void set_error(const char* fmt, ...) {
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// One retired scratch buffer per device, kept for the next plan: the one-shot entry points (a plan per call,
+// the life cycle of the reference's kinds) would otherwise pay a hipMalloc + hipFree — the latter an implicit
+// device synchronisation — on every SpMV.  Only a plan whose stream has been synchronised retires its buffer
+// here (one_shot); mi355_spmv_plan_destroy keeps hipFree's semantics.
+struct RetiredScratch { void* ptr; size_t bytes; };
+static std::mutex g_retired_mutex;
+static RetiredScratch g_retired[64] = {};
+
+static void* take_retired(size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_retired_mutex);
+    RetiredScratch& r = g_retired[dev];
+    if (!r.ptr || r.bytes < bytes || r.bytes > 4 * bytes + (1u << 20)) return nullptr;
+    void* ptr = r.ptr;
+    r.ptr = nullptr;
+    return ptr;
+}
+
+static void retire_scratch(void* ptr, size_t bytes) {
+    int dev = 0;
+    void* old = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        std::lock_guard<std::mutex> lock(g_retired_mutex);
+        old = g_retired[dev].ptr;
+        g_retired[dev] = RetiredScratch{ptr, bytes};
+    } else {
+        old = ptr;
+    }
+    if (old) (void)hipFree(old);
+}
 
 static int plan_alloc_scratch(Plan& p) {
     const size_t val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
@@ -37,7 +74,9 @@ static int plan_alloc_scratch(Plan& p) {
     p.scratch_bytes = off;
     p.scratch = nullptr;
     if (off) {
-        MI355_HIP_TRY(hipMalloc(&p.scratch, off));
+        p.scratch_capacity = off;
+        p.scratch = take_retired(off);
+        if (!p.scratch) MI355_HIP_TRY(hipMalloc(&p.scratch, off));
         char* base = static_cast<char*>(p.scratch);
         p.tile_nnz = reinterpret_cast<int64_t*>(base + o_tile_nnz);
         p.tile_row = reinterpret_cast<int32_t*>(base + o_tile_row);
@@ -87,6 +126,11 @@ static int one_shot(int kind, int off_type, int val_type, int32_t n_rows, int32_
             st = MI355_SPMV_EHIP;
         }
     }
+    // the stream is synchronised: nothing can still touch the plan's scratch, it may serve the next call
+    if (st == MI355_SPMV_OK && plan->p.scratch) {
+        retire_scratch(plan->p.scratch, plan->p.scratch_capacity);
+        plan->p.scratch = nullptr;
+    }
     const int st2 = mi355_spmv_plan_destroy(plan);
     return st != MI355_SPMV_OK ? st : st2;
 }
@@ -94,10 +138,6 @@ static int one_shot(int kind, int off_type, int val_type, int32_t n_rows, int32_
 }  // namespace mi355
 
 using namespace mi355;
-
-struct mi355_spmv_plan {
-    Plan p;
-};
 
 extern "C" {
 

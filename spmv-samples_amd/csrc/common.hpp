@@ -67,7 +67,8 @@ struct Plan {
     // multi-band plan: up to 4 bands of (column - row) found by clustering the probe's samples
     int n_seg;
     int64_t seg_lo[4], seg_hi[4];
-    int probe_n;                 // sampled (column - row) offsets, sorted ascending
+    int probe_n;                 // sampled (column - row) offsets (sorted ascending once probe_sorted)
+    bool probe_sorted;
     int64_t probe_off[8192];
     // row chunks of VECTOR / LIGHT
     int64_t rows_per_chunk;     // uniform plan: every chunk has this many rows
@@ -79,6 +80,7 @@ struct Plan {
     // scratch
     void* scratch;
     size_t scratch_bytes;
+    size_t scratch_capacity;   // bytes of the allocation behind `scratch` (>= scratch_bytes when reused)
     int32_t* tile_row;     // [n_tiles + 1]
     int64_t* tile_nnz;     // [n_tiles + 1]
     int32_t* carry_row;    // [n_super]
