@@ -337,7 +337,8 @@ static int window_budget(const Plan& p, int block_threads, int64_t rows) {
 // div = the kind's chunk divisor (LIGHT's tuning knob).
 // Workgroup size: 512 threads own a chunk twice as long (64 K nonzeros) — the window of x is staged half as
 // often per row and 2 x 8 waves sit on a CU instead of 3 x 4 (LDS-bound either way): 190 -> 178 us on the
-// S32-band target.  VECTOR only (allow_wide): the persistent LIGHT grid lost with it (199 -> 237 us).
+// S32-band target (LIGHT: 199 -> 195 us once its kernel is held to 128 VGPRs; at 151 only one such workgroup
+// fits a CU and it lost, 237 us).
 void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
     auto shape = [&](int block_threads, int64_t nnz_per_chunk) {
         p.block_threads = block_threads;

@@ -82,8 +82,10 @@ __device__ __forceinline__ void light_leave(unsigned long long* __restrict__ cou
     }
 }
 
+// (512 threads: two workgroups per CU need 4 waves per SIMD, i.e. <= 128 VGPRs — the persistent loop's
+// state would otherwise take 151 and leave one workgroup per CU)
 template <int BLOCK, int T, int R, int NSEG, bool ADAPT, typename off_t, typename val_t>
-__global__ __launch_bounds__(BLOCK) void light_rows_window_kernel(
+__global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock ? 4 : 1)) void light_rows_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
     unsigned long long* __restrict__ counters, ChunkMap cmap, int32_t window_cap, BandHint hint,
@@ -187,11 +189,18 @@ __global__ __launch_bounds__(kBlock) void light_rows_kernel(
 template <typename val_t> constexpr int light_rows_in_flight() { return sizeof(val_t) == 4 ? 4 : 2; }
 
 #ifndef MI355_TU_F64   // the host-side shape functions live in the fp32 translation unit only
-static int64_t light_resident(const Plan& p) {
-    // persistent grid: what stays resident — 2 workgroups of 512 threads per CU, or 4 of 256 with the
-    // window of x (5 without: VGPR-bound)
+static int64_t light_resident(const Plan& p, int64_t rows) {
+    // persistent grid = what stays resident on a CU: bounded by LDS (160 KB: the chunk's layout + ~1 KB static)
+    // and by registers (5 workgroups of 256 threads, 2 of 512).  Asking for more than fits leaves the surplus
+    // workgroups to start when the others have finished everything (4 asked / 3 resident: 207 vs 200 us).
     const char* er = getenv("MI355_LIGHT_BLOCKS_PER_CU");
-    const int per_cu = er && atoi(er) > 0 ? atoi(er) : p.block_threads == kWideBlock ? 2 : (p.window_elems ? 4 : 5);
+    if (er && atoi(er) > 0) return int64_t(kCus) * atoi(er);
+    const size_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
+    const size_t lds = chunk_lds_bytes(p.window_elems, int(rows), off_bytes, val_bytes) + 1024;
+    int64_t per_cu = int64_t(160 * 1024 / lds);
+    const int64_t reg_bound = p.block_threads == kWideBlock ? 2 : 5;
+    if (per_cu > reg_bound) per_cu = reg_bound;
+    if (per_cu < 1) per_cu = 1;
     return int64_t(kCus) * per_cu;
 }
 
@@ -201,10 +210,11 @@ void shape_light(Plan& p) {
     const char* ev = getenv("MI355_LIGHT_CHUNK_DIV");
     // chunks: the static kind's size (halving them cost 6 % on the S32-band target: the
     // window of x is staged per chunk), never below one pass of the workgroup
-    shape_chunks(p, R, ev && atoi(ev) > 0 ? atoi(ev) : 1, false);
+    // (512-thread workgroups only with 32-bit offsets: under the 128-VGPR cap the 64-bit kernels spill 80 registers)
+    shape_chunks(p, R, ev && atoi(ev) > 0 ? atoi(ev) : 1, p.off_type == MI355_OFF_I32);
     p.n_tiles = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
     int64_t blocks = p.n_tiles;                     // fewer than resident for small inputs
-    const int64_t resident = light_resident(p);
+    const int64_t resident = light_resident(p, p.rows_per_chunk);
     if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
     p.grid_blocks = blocks;
@@ -220,7 +230,7 @@ void reshape_light_balanced(Plan& p) {
     p.window_bytes = kWindowBytes;
     p.window_elems = pick_window_elems(p, p.rows_cap);
     if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }
-    const int64_t resident = light_resident(p);
+    const int64_t resident = light_resident(p, p.rows_cap);
     p.grid_blocks = p.n_chunks < resident ? p.n_chunks : resident;
     if (p.grid_blocks < 1) p.grid_blocks = 1;
 }
