@@ -29,16 +29,19 @@ if os.path.exists(CMP) and "--no-rocsparse" not in sys.argv:
 
 def rocsparse_direct(m, x, y_ours):
     """{'adaptive': us, 'stream': us, 'analysis_ms': ms, 'rel_maxdiff': d} or None (64-bit offsets)."""
-    if cmp_lib is None or m.Ap.dtype != torch.int32 or m.nnz >= 2 ** 31:
+    if cmp_lib is None or m.nnz >= 2 ** 31:
         return None
     import ctypes
     res = {}
+    Ap32 = m.Ap if m.Ap.dtype == torch.int32 else m.Ap.to(torch.int32)   # csrmv takes 32-bit row offsets
+    if Ap32 is not m.Ap:
+        res["note"] = "vendor run on a 32-bit-offset copy of Ap"
     y = torch.full_like(y_ours, float("nan"))
     for name, analyse in (("stream", 0), ("adaptive", 1)):
         us, ana = ctypes.c_double(0), ctypes.c_double(0)
         torch.cuda.synchronize()
         rc = cmp_lib.cmp_rocsparse_csrmv(0 if m.Ax.dtype == torch.float32 else 1, m.n_rows, m.n_cols, m.nnz,
-                                         m.Ap.data_ptr(), m.Aj.data_ptr(), m.Ax.data_ptr(), x.data_ptr(),
+                                         Ap32.data_ptr(), m.Aj.data_ptr(), m.Ax.data_ptr(), x.data_ptr(),
                                          y.data_ptr(), analyse, 5, 30, ctypes.byref(us), ctypes.byref(ana))
         assert rc == 0
         torch.cuda.synchronize()
@@ -50,14 +53,14 @@ def rocsparse_direct(m, x, y_ours):
 
 for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["s32-band", "c2-cant", "c3-webgoogle"]):
     m = sp.synth.workload(w, dev)
-    if m.Ap.dtype != m.Aj.dtype:
-        # torch.sparse_csr_tensor does not validate index dtypes by default; int64 crow + int32 col
-        # indices faulted inside the vendor path (MI355X, torch 2.10/ROCm 7.0): never run that
-        print(w, "skipped: mixed index dtypes are not safe to hand to torch.sparse")
-        continue
+    with_torch = m.Ap.dtype == m.Aj.dtype and "--no-torch-sparse" not in sys.argv
+    # (torch.sparse_csr_tensor does not validate index dtypes by default; int64 crow + int32 col indices faulted
+    # inside the vendor path on MI355X, torch 2.10/ROCm 7.0: mixed dtypes are never handed to it)
     x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, dev)
-    A = torch.sparse_csr_tensor(m.Ap, m.Aj, m.Ax, size=(m.n_rows, m.n_cols))
-    y = A @ x
+    y = torch.zeros(m.n_rows, dtype=m.Ax.dtype, device=dev)
+    if with_torch:
+        A = torch.sparse_csr_tensor(m.Ap, m.Aj, m.Ax, size=(m.n_rows, m.n_cols))
+        y = A @ x
     # our engine on the same operands, for the cross-check and the side-by-side time
     res = {}
     y2 = torch.empty_like(y)
@@ -74,20 +77,22 @@ for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["s32-band", "c
         torch.cuda.synchronize()
         res[kind] = a.elapsed_time(b) / 30 * 1e3
         p.destroy()
-    err = float((y2 - y).abs().max() / (y.abs().max() + 1e-30))
     direct = rocsparse_direct(m, x, y2)
-    for _ in range(5):
-        y = A @ x
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(30):
-        y = A @ x
-    b.record()
-    torch.cuda.synchronize()
-    t = a.elapsed_time(b) / 30 * 1e3
-    out[w] = {"vendor_torch_sparse_us": t, "ours_us": res, "rel_maxdiff_vs_vendor": err,
-              "algorithmic_GBps_vendor": m.algorithmic_bytes() / t / 1e3, "rocsparse_csrmv": direct}
+    t, err = None, None
+    if with_torch:
+        err = float((y2 - y).abs().max() / (y.abs().max() + 1e-30))
+        for _ in range(5):
+            y = A @ x
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(30):
+            y = A @ x
+        b.record()
+        torch.cuda.synchronize()
+        t = a.elapsed_time(b) / 30 * 1e3
+        del A
+    out[w] = {"vendor_torch_sparse_us": t, "ours_us": res, "rel_maxdiff_vs_vendor": err, "rocsparse_csrmv": direct}
     print(w, json.dumps(out[w]), flush=True)
-    del A, m, x, y, y2
+    del m, x, y, y2
     torch.cuda.empty_cache()

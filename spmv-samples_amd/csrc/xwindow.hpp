@@ -58,16 +58,29 @@ template <typename val_t>
 struct XWindowN {
     const val_t* s_x;
     int32_t lo[kMaxSegments], len[kMaxSegments], off[kMaxSegments];
-    __device__ __forceinline__ bool find(int32_t col, unsigned& idx) const {
-        bool in = false;
-        idx = 0u;
+    // derived by finish(): the segments are disjoint and ascending, so the one a column can be in is the last
+    // whose start it reaches — one compare and two selects per segment instead of a full range test each
+    int32_t thr[kMaxSegments];    // start of segment s (INT32_MAX for an empty one)
+    int32_t shift[kMaxSegments];  // lo[s] - off[s]: LDS index = col - shift
+    int32_t end[kMaxSegments];    // lo[s] + len[s]
+    __device__ __forceinline__ void finish() {
 #pragma unroll
         for (int s = 0; s < kMaxSegments; ++s) {
-            const unsigned rel = unsigned(col - lo[s]);
-            const bool ins = rel < unsigned(len[s]);
-            idx = ins ? unsigned(off[s]) + rel : idx;
-            in |= ins;
+            thr[s] = len[s] > 0 ? lo[s] : INT32_MAX;
+            shift[s] = lo[s] - off[s];
+            end[s] = len[s] > 0 ? lo[s] + len[s] : INT32_MIN;
         }
+    }
+    __device__ __forceinline__ bool find(int32_t col, unsigned& idx) const {
+        int32_t sh = shift[0], en = end[0];
+#pragma unroll
+        for (int s = 1; s < kMaxSegments; ++s) {
+            const bool at = col >= thr[s];
+            sh = at ? shift[s] : sh;
+            en = at ? end[s] : en;
+        }
+        const bool in = (col >= thr[0]) & (col < en);
+        idx = in ? unsigned(col - sh) : 0u;
         return in;
     }
 };
@@ -216,6 +229,7 @@ __device__ __forceinline__ XWindowN<val_t> stage_x_segments(int64_t rb, int64_t 
         for (int i = full * PER16 + tid; i < len; i += int(blockDim.x)) s_x[off + i] = x[lo + i];
         off += (len + PER16 - 1) & ~(PER16 - 1);
     }
+    win.finish();
     __syncthreads();
     return win;
 }
@@ -378,14 +392,18 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     // outside it is fetched and consumed under ONE branch per 4 elements, so the common path
     // never waits on vector memory.  !WINDOW: plain gathers (masked elements hold a legal
     // column of a neighbouring row, or 0, so the address is always in range).
+    // (the valid elements are e in [e_lo, e_hi): the callers turn the row bounds into these two small ints once
+    // per 4 elements, so the per-element test is 32-bit whatever off_t is)
     auto accumulate = [&](val_t& sum, const int4v& c, const v4& a, off_t j, off_t lo, off_t hi) {
+        const off_t d_lo = lo - j, d_hi = hi - j;
+        const int e_lo = d_lo > 0 ? int(d_lo) : 0;                 // lo - j <= 3 wherever this is called
+        const int e_hi = d_hi < 4 ? (d_hi > 0 ? int(d_hi) : 0) : 4;
         if constexpr (WINDOW) {
             bool need[4];
             bool any_need = false;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const off_t k = j + e;
-                const bool valid = (k >= lo) && (k < hi);
+                const bool valid = (e >= e_lo) & (e < e_hi);
                 unsigned idx;
                 const bool in = win.find(c[e], idx);
                 const val_t xv = win.s_x[idx];
@@ -404,10 +422,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[e] = x[c[e]];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const off_t k = j + e;
-                sum = ((k >= lo) && (k < hi)) ? (sum + a[e] * xv[e]) : sum;
-            }
+            for (int e = 0; e < 4; ++e) sum = ((e >= e_lo) & (e < e_hi)) ? (sum + a[e] * xv[e]) : sum;
         }
     };
     auto consume = [&](int g, const Group& G) {
