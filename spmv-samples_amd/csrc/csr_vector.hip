@@ -38,14 +38,17 @@ __global__ __launch_bounds__(BLOCK) void csr_vector_window_kernel(
     int64_t rb, re;
     cmap.range(chunk, n_rows, rb, re);
     if (rb >= re) return;   // (balanced plans: a hub row heavier than a chunk leaves empty chunks behind it)
-    stage_chunk_bounds<off_t, val_t>(scr, rb, re, Ap);      // ordered before chunk_rows by the barrier below
+    stage_chunk_bounds<off_t, val_t>(scr, rb, re, Ap);
+    __syncthreads();
+    // the window is staged inside chunk_rows, behind the first group's stream loads
     if constexpr (NSEG > 1) {
-        const XWindowN<val_t> win = stage_x_segments<val_t>(rb, re, n_cols, x, scr.s_x, window_cap, segs);
-        chunk_rows_any<BLOCK, T, R, true, ADAPT, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
+        auto stage = [&] { return stage_x_segments<val_t>(rb, re, n_cols, x, scr.s_x, window_cap, segs); };
+        chunk_rows_any<BLOCK, T, R, true, ADAPT, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, stage, scr);
     } else {
-        const XWindow<val_t> win =
-            stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
-        chunk_rows_any<BLOCK, T, R, NSEG == 1, ADAPT, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, win, scr);
+        auto stage = [&] {
+            return stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
+        };
+        chunk_rows_any<BLOCK, T, R, NSEG == 1, ADAPT, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, stage, scr);
     }
 }
 

@@ -124,16 +124,20 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock ? 4 : 1)) void light_ro
                 __syncthreads();              // s_got read by all before the next dequeue overwrites it
                 continue;
             }
-            // (stage_x_window's barriers also order this read of s_got before the next write)
-            stage_chunk_bounds<off_t, val_t>(scr, chunk_begin, chunk_end, Ap);   // before the barrier below
+            stage_chunk_bounds<off_t, val_t>(scr, chunk_begin, chunk_end, Ap);
+            __syncthreads();      // (also orders this read of s_got before the next dequeue writes it)
+            // the window is staged inside chunk_rows, behind the first group's stream loads
             if constexpr (NSEG > 1) {
-                const XWindowN<val_t> win =
-                    stage_x_segments<val_t>(chunk_begin, chunk_end, n_cols, x, scr.s_x, window_cap, segs);
-                chunk_rows_any<BLOCK, T, R, true, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+                auto stage = [&] {
+                    return stage_x_segments<val_t>(chunk_begin, chunk_end, n_cols, x, scr.s_x, window_cap, segs);
+                };
+                chunk_rows_any<BLOCK, T, R, true, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
             } else {
-                const XWindow<val_t> win = stage_x_window<off_t, val_t>(
-                    chunk_begin, chunk_end, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
-                chunk_rows_any<BLOCK, T, R, NSEG == 1, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+                auto stage = [&] {
+                    return stage_x_window<off_t, val_t>(chunk_begin, chunk_end, n_cols, Ap, Aj, x, scr.s_x, window_cap,
+                                                        s_red, hint);
+                };
+                chunk_rows_any<BLOCK, T, R, NSEG == 1, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
             }
             __syncthreads();  // every wave is done with the window before it is refilled
         }

@@ -347,13 +347,16 @@ __device__ __forceinline__ void load_group(off_t j, off_t nnz, const int32_t* __
 //    would serialise the chunk behind one vector — the weakness of the reference's
 //    CSR-vector and LightSpMV kernels): its bit is set in an LDS bitmap and a second pass
 //    sums every marked row with a whole 64-lane wave, the four waves taking rows in turn.
+//  * the window of x is staged AFTER the first group's stream loads are issued (`stage` is the
+//    caller's staging function: its loads, LDS writes and closing barrier run while those loads
+//    are in flight), so a chunk's prologue costs one memory round trip, not two.
 // All BLOCK threads of the workgroup must call (wave-wide shuffles and barriers inside); the caller
-// has run stage_chunk_bounds + a barrier.
-template <int BLOCK, int T, int R, bool WINDOW, typename off_t, typename val_t, typename Win>
+// has run stage_chunk_bounds + a barrier; `stage()` returns the window and ends with a barrier.
+template <int BLOCK, int T, int R, bool WINDOW, typename off_t, typename val_t, typename StageFn>
 __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_end, off_t nnz,
                                            const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
                                            const val_t* __restrict__ Ax, const val_t* __restrict__ x,
-                                           val_t* __restrict__ y, const Win& win,
+                                           val_t* __restrict__ y, StageFn&& stage,
                                            const ChunkScratch<off_t, val_t>& scr) {
     using v4 = typename Vec4<val_t>::type;
     constexpr int VECS = BLOCK / T;
@@ -387,6 +390,10 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
             G.a[r] = stream_load(reinterpret_cast<const v4*>(Ax + jl));
         }
     };
+    Group G0, G1;
+    issue(0, G0);                 // in flight while the window is staged
+    const auto win = stage();     // (workgroup barrier inside)
+
     // sum += a[e] * x[c[e]] for the elements k = j+e inside [lo, hi).  WINDOW: x comes from the
     // LDS window (unconditional ds_read at a clamped address + select); the rare column
     // outside it is fetched and consumed under ONE branch per 4 elements, so the common path
@@ -480,8 +487,6 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     };
 
     {
-        Group G0, G1;
-        issue(0, G0);
         for (int g = 0; g < n_groups; g += 2) {
             issue(g + 1, G1);
             consume(g, G0);
@@ -617,20 +622,20 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
 // 2 000 near-empty rows and chunks of 100 rows x 120 nonzeros; one width for all of them leaves the second
 // kind walking 16 dependent steps per row.  Three widths (2, 8, 32 lanes: rows of <= 8, 32, 128 nonzeros in
 // one step) from the chunk's own mean row length, read from the bounds already in LDS.
-template <int BLOCK, int T, int R, bool WINDOW, bool ADAPT, typename off_t, typename val_t, typename Win>
+template <int BLOCK, int T, int R, bool WINDOW, bool ADAPT, typename off_t, typename val_t, typename StageFn>
 __device__ __forceinline__ void chunk_rows_any(int64_t chunk_begin, int64_t chunk_end, off_t nnz,
                                                const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
                                                const val_t* __restrict__ Ax, const val_t* __restrict__ x,
-                                               val_t* __restrict__ y, const Win& win,
+                                               val_t* __restrict__ y, StageFn&& stage,
                                                const ChunkScratch<off_t, val_t>& scr) {
     if constexpr (!ADAPT) {
-        chunk_rows<BLOCK, T, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+        chunk_rows<BLOCK, T, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
     } else {
         const int rows = int(chunk_end - chunk_begin);
         const off_t mean = (scr.s_b[rows] - scr.s_b[0]) / off_t(rows > 0 ? rows : 1);   // uniform over the workgroup
-        if (mean <= 16) chunk_rows<BLOCK, 2, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
-        else if (mean <= 64) chunk_rows<BLOCK, 8, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
-        else chunk_rows<BLOCK, 32, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, win, scr);
+        if (mean <= 16) chunk_rows<BLOCK, 2, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
+        else if (mean <= 64) chunk_rows<BLOCK, 8, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
+        else chunk_rows<BLOCK, 32, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
     }
 }
 
