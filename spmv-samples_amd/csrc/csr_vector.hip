@@ -185,7 +185,8 @@ int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* 
     // that passes an offset view gets the 4-byte-per-lane form instead.
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
-    if (aligned && p.nnz >= 4)
+    static const bool force_plain = [] { const char* e = getenv("MI355_SPMV_PLAIN"); return e && atoi(e) != 0; }();   // tuning / tests
+    if (aligned && p.nnz >= 4 && !force_plain)
         return p.block_threads == kWideBlock ? launch_vector_window<kWideBlock, off_t, val_t>(p, Ap, Ax, x, y, s)
                                              : launch_vector_window<kBlock, off_t, val_t>(p, Ap, Ax, x, y, s);
     return launch_vector_plain<off_t, val_t>(p, Ap, Ax, x, y, s);

@@ -247,6 +247,11 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
                 }
             }
             if (y1 > nnz_vec) {   // uniform, at most one tile: the nonzeros past the last whole group
+                // Their slots were just written — with the products of the clamped group — by the thread whose
+                // 16-byte store covers them, usually in another wave: the corrective stores must come after
+                // that store, hence the barrier (without it the last row of a matrix with nnz % 4 != 0 was
+                // wrong about once in 25 processes).
+                __syncthreads();
                 const int64_t k = (y0 > nnz_vec ? y0 : nnz_vec) + tid;
                 if (k < y1) s_nz[int(k - y0) + shift] = SR::combine(Ax[k], x[Aj[k]]);
             }

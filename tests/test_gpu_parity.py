@@ -192,6 +192,39 @@ def test_run_to_run_bitwise_reproducible(sp, kind):
         assert np.array_equal(a, gpu_spmv(sp, kind, 4000, Ap, Aj, Ax, x))
 
 
+@pytest.mark.parametrize("tail", [1, 2, 3])
+def test_array_tail_is_race_free(sp, oracle, tail):
+    """nnz % 4 != 0: the last 1-3 nonzeros of the arrays cannot be read with a 16-byte load and are redone
+    by a scalar path.  In the merge kernel that path rewrites LDS slots another wave has just written
+    (regression: without a barrier in between, the last row came out wrong in about one process out of 25 on
+    the C4 stand-in).  Integer-valued data: every repetition must equal the serial CPU result bit for bit."""
+    rng = np.random.RandomState(50 + tail)
+    n_rows, n_cols = 4000, 900
+    lens = rng.randint(20, 40, size=n_rows)
+    lens[-1] = 37
+    while int(lens.sum()) % 4 != tail:
+        lens[rng.randint(0, n_rows - 1)] += 1
+    Ap = np.zeros(n_rows + 1, dtype=np.int32)
+    np.cumsum(lens, out=Ap[1:])
+    nnz = int(Ap[-1])
+    assert nnz % 4 == tail
+    Aj = rng.randint(0, n_cols, size=nnz).astype(np.int32)
+    Ax = rng.randint(-3, 4, size=nnz).astype(np.float32)
+    x = rng.randint(-2, 3, size=n_cols).astype(np.float32)
+    want = torch.from_numpy(oracle.spmv_serial(Ap, Aj, Ax, x)).to(DEV)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    dAp, dAj, dAx, dx = d(Ap), d(Aj), d(Ax), d(x)
+    for kind in KINDS:
+        p = sp.Plan(kind, n_rows, n_cols, nnz, dAp, dAj, torch.float32)
+        y = torch.empty(n_rows, device=DEV)
+        for rep in range(150):
+            y.fill_(float("nan"))
+            p.execute(dAx, dx, y)
+            assert torch.equal(y, want), (kind, rep, torch.nonzero(y != want).flatten()[:4].tolist())
+        p.destroy()
+
+
+@pytest.mark.skipif(bool(os.environ.get("MI355_SPMV_PLAIN")), reason="the forced 4-byte kernel sums in another order")
 def test_vector_and_light_agree_bitwise(sp):
     """Both use the same per-row arithmetic; only the row -> wave assignment differs
     (results are assignment-independent)."""
@@ -356,7 +389,10 @@ def test_full_size_fp64_i64_linearity_and_rowsums(sp, oracle, kind):
     sp.spmv(kind, n, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax, xa, ya)
     sp.spmv(kind, n, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax, xb, yb)
     sp.spmv(kind, n, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax, 2.0 * xa - 0.5 * xb, yc)
-    assert torch.allclose(yc, 2.0 * ya - 0.5 * yb, rtol=0, atol=1e-12 * 28 * 4)
+    lin_err = (yc - (2.0 * ya - 0.5 * yb)).abs()
+    bad = torch.nonzero(~(lin_err <= 1e-12 * 28 * 4)).flatten()
+    assert bad.numel() == 0, "linearity: %d rows off, first %s, errors %s, yc %s" % (
+        bad.numel(), bad[:6].tolist(), lin_err[bad[:6]].tolist(), yc[bad[:6]].tolist())
     rows = 200000
     hi = int(m.Ap[rows].item())
     Ap = m.Ap[:rows + 1].cpu().numpy(); Aj = m.Aj[:hi].cpu().numpy(); Ax = m.Ax[:hi].cpu().numpy()
