@@ -152,14 +152,10 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     const int64_t first = int64_t(sup) * tiles_per_super;
     const int64_t last = min(first + tiles_per_super, n_tiles);
 
-    // the window of x for all rows this run touches (incl. the row left open at its end)
-    const int64_t row_lo = tile_row[first];
-    const int64_t row_hi = min(int64_t(tile_row[last]) + 1, int64_t(n_rows));
-    const XWindow<val_t> win =
-        stage_x_window<off_t, val_t>(row_lo, row_hi, n_cols, Ap, Aj, x, s_x, window_cap, s_red, hint);
-
     int x0 = tile_row[first], x1 = tile_row[first + 1];
     int64_t y0 = tile_nnz[first], y1 = tile_nnz[first + 1];
+    const int64_t row_lo = x0;
+    const int64_t row_hi = min(int64_t(tile_row[last]) + 1, int64_t(n_rows));
 
     // registers holding the Aj/Ax groups of the tile about to be processed
     int4v c[G];
@@ -179,6 +175,10 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
         }
     };
     if constexpr (VEC) issue(y0);
+    // the window of x for all rows this run touches (incl. the row left open at its end), staged while the
+    // first tile's stream is in flight
+    const XWindow<val_t> win =
+        stage_x_window<off_t, val_t>(row_lo, row_hi, n_cols, Ap, Aj, x, s_x, window_cap, s_red, hint);
     // the first kBlock row ends of a tile are fetched one tile ahead as well (a tile with more
     // rows than that — mean row length below 8 — loads the rest when it gets there)
     auto fetch_row_end = [&](int xa, int xe) -> int64_t {
