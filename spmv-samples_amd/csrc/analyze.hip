@@ -356,11 +356,16 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
         p.window_elems = pick_window_elems(p, rows);
         if (const int64_t fit = segment_rows_fit(p)) {   // several bands: shrink the chunk until they all fit
             if (fit < p.rows_per_chunk && fit >= pass) p.rows_per_chunk = fit / pass * pass;
+            // ... and take only the LDS the bands need with that many rows (LDS is occupancy)
+            int64_t need = 0;
+            for (int i = 0; i < p.n_seg; ++i) need += p.seg_hi[i] - p.seg_lo[i] + 1 + 4 + p.rows_per_chunk;
+            need = (need + 3) & ~int64_t(3);
+            if (need < p.window_elems) p.window_elems = int(need);
         }
     };
     const char* force = getenv("MI355_SPMV_BLOCK");
     if (force ? atoi(force) == kWideBlock : allow_wide) {
-        shape(kWideBlock, 65536);
+        shape(kWideBlock, 65536);   // (3 072- and 3 584-row chunks with 79 KB of LDS measured worse: 189-194 vs 180 us)
         const int64_t mean = p.n_rows > 0 ? (p.nnz + p.n_rows - 1) / p.n_rows : 1;
         // keep it when (a) the ">= 4 chunks per CU" rule left the chunk long and (b) one window placed from the
         // band serves it (with 64-bit offsets / fp64 / several bands the 64 KB a launch may take is better spent
