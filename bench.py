@@ -101,7 +101,7 @@ def time_steps(plan, m, x, y_local, y_full, cuts, use_dist, steps, sp):
     t0 = time.perf_counter()
     for i, (a, b) in enumerate(evs):
         k = i & 1
-        if pending[k] is not None:
+        if pending[k] is not None and not pending[k].done():   # (a finished exchange needs no stream-level wait)
             pending[k].wait()
         a.record()
         plan.execute(m.Ax, x, y_local[k])
