@@ -22,8 +22,10 @@
 
 namespace mi355 {
 
+// (512 threads: two workgroups per CU need 4 waves per SIMD, i.e. <= 128 VGPRs; the fp32 / 32-bit-offset
+// kernel sits at 127 — the bound keeps a later edit from silently halving the occupancy)
 template <int BLOCK, int T, int R, int NSEG, bool ADAPT, typename off_t, typename val_t>
-__global__ __launch_bounds__(BLOCK) void csr_vector_window_kernel(
+__global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock ? 4 : 1)) void csr_vector_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, ChunkMap cmap,
     int32_t window_cap, BandHint hint, SegmentPlan segs, val_t alpha, val_t beta) {
@@ -83,7 +85,8 @@ void shape_vector(Plan& p) {
         const int t = atoi(e);
         if (t == 2 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64) p.lanes_per_row = t;
     }
-    shape_chunks(p, R, 1, true);     // workgroup size, rows per chunk, window of x (analyze.hip)
+    // (512-thread workgroups only with 32-bit offsets: the 64-bit-offset kernels need 120-190 VGPRs)
+    shape_chunks(p, R, 1, p.off_type == MI355_OFF_I32);     // workgroup size, rows per chunk, window of x (analyze.hip)
     p.grid_blocks = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
     if (p.grid_blocks < 1) p.grid_blocks = 1;
     p.n_tiles = p.grid_blocks;
