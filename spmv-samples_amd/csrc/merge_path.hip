@@ -127,8 +127,8 @@ __global__ __launch_bounds__(kBlock) void merge_search_kernel(
 }
 
 // ---- K7: one run of consecutive tiles per workgroup ---------------------------------
-template <int IPT, bool VEC, bool WINDOW, int S, typename off_t, typename val_t>
-__global__ __launch_bounds__(kBlock) void merge_tile_kernel(
+template <int BLOCK, int IPT, bool VEC, bool WINDOW, int S, typename off_t, typename val_t>
+__global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
     int32_t n_rows, int32_t n_cols, int64_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
     const int32_t* __restrict__ tile_row, const int64_t* __restrict__ tile_nnz,
@@ -138,10 +138,10 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     using v4 = typename Vec4<val_t>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window_cap values of x
     val_t* s_x = reinterpret_cast<val_t*>(s_dyn);
-    __shared__ __attribute__((aligned(32))) val_t s_nz[kBlock * IPT];   // products, index = nnz - (y0 & ~3)
-    __shared__ int s_re[kBlock * IPT + 1];                               // tile-relative row ends
-    __shared__ val_t s_wave_sum[kBlock / kWave];
-    __shared__ int s_wave_flag[kBlock / kWave];
+    __shared__ __attribute__((aligned(32))) val_t s_nz[BLOCK * IPT];   // products, index = nnz - (y0 & ~3)
+    __shared__ int s_re[BLOCK * IPT + 1];                               // tile-relative row ends
+    __shared__ val_t s_wave_sum[BLOCK / kWave];
+    __shared__ int s_wave_flag[BLOCK / kWave];
     __shared__ val_t s_carry;
     __shared__ int s_red[2];
 
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
         const int64_t base = ya & ~int64_t(3);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            int64_t j = base + 4 * int64_t(tid + g * kBlock);
+            int64_t j = base + 4 * int64_t(tid + g * BLOCK);
             j = j < j_max ? j : j_max;
             c[g] = stream_load(reinterpret_cast<const int4v*>(Aj + j));
             a[g] = stream_load(reinterpret_cast<const v4*>(Ax + j));
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
     // first tile's stream is in flight
     const XWindow<val_t> win =
         stage_x_window<off_t, val_t>(row_lo, row_hi, n_cols, Ap, Aj, x, s_x, window_cap, s_red, hint);
-    // the first kBlock row ends of a tile are fetched one tile ahead as well (a tile with more
+    // the first BLOCK row ends of a tile are fetched one tile ahead as well (a tile with more
     // rows than that — mean row length below 8 — loads the rest when it gets there)
     auto fetch_row_end = [&](int xa, int xe) -> int64_t {
         return (tid < xe - xa) ? int64_t(Ap[int64_t(xa) + tid + 1]) : int64_t(0);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
             if constexpr (WINDOW) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const int rel0 = 4 * (tid + g * kBlock) - shift;   // tile-relative index of element 0
+                    const int rel0 = 4 * (tid + g * BLOCK) - shift;   // tile-relative index of element 0
                     v4 p;
                     bool need[4];
                     bool any_need = false;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
                             if (need[e]) p[e] = SR::combine(a[g][e], x[c[g][e]]);
                         }
                     }
-                    *reinterpret_cast<v4*>(&s_nz[4 * (tid + g * kBlock)]) = p;
+                    *reinterpret_cast<v4*>(&s_nz[4 * (tid + g * BLOCK)]) = p;
                 }
             } else {
                 val_t xv[G][4];
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
                     v4 p;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) p[e] = SR::combine(a[g][e], xv[g][e]);
-                    *reinterpret_cast<v4*>(&s_nz[4 * (tid + g * kBlock)]) = p;
+                    *reinterpret_cast<v4*>(&s_nz[4 * (tid + g * BLOCK)]) = p;
                 }
             }
             if (y1 > nnz_vec) {   // uniform, at most one tile: the nonzeros past the last whole group
@@ -259,14 +259,14 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
             if (t + 1 < last) issue(y1);
         } else {
             // Aj / Ax not 16-byte aligned (an offset view): 4-byte-per-lane form
-            for (int i = tid; i < tn; i += kBlock) {
+            for (int i = tid; i < tn; i += BLOCK) {
                 const int32_t col = Aj[y0 + i];
                 s_nz[i] = SR::combine(Ax[y0 + i], window_gather<val_t>(win, x, col, true));
             }
         }
         // (2) row ends, relative to y0; the row still open at the tile end never ends here
         if (tid <= tr) s_re[tid] = (tid < tr) ? int(re_next - y0) : INT_MAX;
-        for (int i = tid + kBlock; i <= tr; i += kBlock) {
+        for (int i = tid + BLOCK; i <= tr; i += BLOCK) {
             s_re[i] = (i < tr) ? int(int64_t(Ap[int64_t(x0) + i + 1]) - y0) : INT_MAX;
         }
         if (t + 1 < last) re_next = fetch_row_end(x1, x2);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void merge_tile_kernel(
         val_t carry_in = __shfl_up(incl, 1, kWave);
         if (lane64 == 0) carry_in = prefix;
         if (first_end >= 0) put(int64_t(x0) + first_end, SR::reduce(carry_in, first_val));
-        if (tid == kBlock - 1) s_carry = incl;   // the row still open at the end of the tile
+        if (tid == BLOCK - 1) s_carry = incl;   // the row still open at the end of the tile
         __syncthreads();                          // also frees s_nz / s_re / s_wave_* for the next tile
         block_carry = s_carry;
         x0 = x1; y0 = y1;
@@ -375,10 +375,12 @@ static int env_int(const char* name, int dflt) {
 
 void shape_merge(Plan& p) {
     // tuning knobs: MI355_MERGE_TPS = tiles per run (and MI355_SPMV_WINDOW = 0|1, analyze.hip)
-    const int ipt = 8;   // (16 measured no better; one instantiation per semiring instead)
+    // 256 threads x 8 items or (MI355_MERGE_BLOCK=512) 512 threads x 4 items: the same 2 044-item tiles
+    p.block_threads = env_int("MI355_MERGE_BLOCK", kBlock) == kWideBlock ? kWideBlock : kBlock;
+    const int ipt = p.block_threads == kWideBlock ? 4 : 8;   // (16 measured no better)
     p.lanes_per_row = 0;
     p.elems_per_lane = ipt;            // reported as items per thread for this kind
-    p.tile_items = int64_t(kBlock) * ipt - 4;
+    p.tile_items = int64_t(p.block_threads) * ipt - 4;
     const int64_t items = int64_t(p.n_rows) + p.nnz;
     p.n_tiles = (items + p.tile_items - 1) / p.tile_items;
     // runs of up to ~32 K items, but at least ~4 runs per CU when the matrix allows
@@ -430,11 +432,20 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
     const int32_t cap = (aligned && p.nnz >= 4) ? (int32_t)p.window_elems : 0;
     const size_t dyn = size_t(cap) * sizeof(val_t);
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
-    const dim3 grid((unsigned)p.n_super), block(kBlock);
+    const dim3 grid((unsigned)p.n_super);
+    const bool wide = p.block_threads == kWideBlock && p.semiring == MI355_SEMIRING_PLUS_TIMES;
+#define MI355_MERGE_ARGS dyn, s, p.n_rows, p.n_cols, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz, p.carry_row, \
+                       static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super, cap, hint, (val_t)p.alpha, (val_t)p.beta
 #define MI355_MERGE_LAUNCH(VEC_, WIN_, S_)                                                                    \
-    hipLaunchKernelGGL((merge_tile_kernel<8, VEC_, WIN_, S_, off_t, val_t>), grid, block, dyn, s, p.n_rows,    \
-                       p.n_cols, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz, p.carry_row,              \
-                       static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super, cap, hint, (val_t)p.alpha, (val_t)p.beta)
+    do {                                                                                                      \
+        if constexpr (S_ == MI355_SEMIRING_PLUS_TIMES) {                                                      \
+            if (wide) {                                                                                       \
+                hipLaunchKernelGGL((merge_tile_kernel<kWideBlock, 4, VEC_, WIN_, S_, off_t, val_t>), grid, dim3(kWideBlock), MI355_MERGE_ARGS); \
+                break;                                                                                        \
+            }                                                                                                 \
+        }                                                                                                     \
+        hipLaunchKernelGGL((merge_tile_kernel<kBlock, 8, VEC_, WIN_, S_, off_t, val_t>), grid, dim3(kBlock), MI355_MERGE_ARGS); \
+    } while (0)
 #define MI355_MERGE_SEMIRING(S_)                                                    \
     do {                                                                            \
         if (!vec) MI355_MERGE_LAUNCH(false, false, S_);                             \
@@ -459,6 +470,7 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
     }
 #undef MI355_MERGE_SEMIRING
 #undef MI355_MERGE_LAUNCH
+#undef MI355_MERGE_ARGS
     return MI355_SPMV_OK;
 }
 
