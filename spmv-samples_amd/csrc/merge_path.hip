@@ -289,22 +289,51 @@ __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
         int first_end = -1;
         int re = s_re[cx];
         const int cnt = d1 - d0;
+        // Rows longer than a thread's IPT items (the banded target, FEM matrices, stencils) put at most ONE row
+        // end among them: the items are then `before` nonzeros, the row end, and the rest nonzeros of the next
+        // row — contiguous in s_nz.  When that holds for every thread of the wave, the item-by-item walk (IPT
+        // dependent LDS reads and branches) is replaced by IPT independent reads and two masked sums, in the
+        // same order, so the result is the same bit for bit.  Otherwise the wave walks.
+        const int before = re - cy;                                   // nonzeros ahead of my first row end
+        const bool has_end = before < cnt;
+        const int re2 = (has_end && cx + 1 <= tr) ? s_re[cx + 1] : INT_MAX;
+        const bool simple = !has_end || (re2 - re >= cnt - before - 1);
+        if (__all(simple)) {
+            const int n_nz = cnt - (has_end ? 1 : 0);                 // my nonzeros: s_nz[cy + shift .. + n_nz)
+            val_t v[IPT];
 #pragma unroll
-        for (int k = 0; k < IPT; ++k) {
-            if (k < cnt) {
-                if (cy < re) {
-                    run = SR::reduce(run, s_nz[cy + shift]);
-                    ++cy;
-                } else {
-                    if (first_end < 0) {
-                        first_end = cx;                   // may continue a row opened by earlier threads
-                        first_val = run;
+            for (int k = 0; k < IPT; ++k) v[k] = s_nz[min(cy + shift + k, BLOCK * IPT - 1)];
+            val_t head = SR::identity(), tail = SR::identity();
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                head = (k < before && k < n_nz) ? SR::reduce(head, v[k]) : head;
+                tail = (k >= before && k < n_nz) ? SR::reduce(tail, v[k]) : tail;
+            }
+            if (has_end) {
+                first_end = cx;                           // may continue a row opened by earlier threads
+                first_val = head;
+                run = tail;
+            } else {
+                run = head;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                if (k < cnt) {
+                    if (cy < re) {
+                        run = SR::reduce(run, s_nz[cy + shift]);
+                        ++cy;
                     } else {
-                        put(int64_t(x0) + cx, run);       // opened and closed inside this thread
+                        if (first_end < 0) {
+                            first_end = cx;                   // may continue a row opened by earlier threads
+                            first_val = run;
+                        } else {
+                            put(int64_t(x0) + cx, run);       // opened and closed inside this thread
+                        }
+                        run = SR::identity();
+                        ++cx;
+                        re = s_re[cx];
                     }
-                    run = SR::identity();
-                    ++cx;
-                    re = s_re[cx];
                 }
             }
         }
