@@ -131,7 +131,7 @@ def cpu_baseline(m, x, budget_s):
     run()  # warm-up (page-in)
     times = []
     t_end = time.perf_counter() + budget_s
-    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 50):
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 400):
         t0 = time.perf_counter()
         run()
         times.append(time.perf_counter() - t0)

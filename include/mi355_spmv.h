@@ -118,8 +118,15 @@ MI355_SPMV_DECLARE_GENL(i64_f64, int64_t, double)
  * The reference re-creates scratch on every call (quirks 7-9 of SURVEY.md §2c);
  * a plan keeps scratch and launch shapes across the timing loop of main.cu:102-113.
  * create: sizes + structure pointers (Ap/Aj are retained, not copied, and must
- *         outlive the plan).  execute: asynchronous on `stream`, no host sync,
- *         no allocation (hipGraph-capturable).  destroy: frees scratch.        */
+ *         outlive the plan; their CONTENTS are read here — a structure probe and,
+ *         for VECTOR / LIGHT, the chunk boundaries — so they must already be valid
+ *         and must not change while the plan lives).  Synchronises the device.
+ * execute: asynchronous on `stream`, no host sync, no allocation, kernels only
+ *         (hipGraph-capturable: tests/test_gpu_parity.py).  A plan serves ONE
+ *         stream at a time (its scratch — merge coordinates and carries, the LIGHT
+ *         counters — belongs to the execute in flight); concurrent executes need
+ *         one plan each.
+ * destroy: frees scratch (hipFree: waits for the device).                      */
 typedef struct mi355_spmv_plan mi355_spmv_plan;
 
 int mi355_spmv_plan_create(mi355_spmv_plan** plan, int kind, int off_type, int val_type,
