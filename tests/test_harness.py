@@ -105,3 +105,22 @@ def test_harness_on_a_generated_banded_file(exe, tmp_path):
     assert "n_rows: 40000  n_cols: 40000  nnz: 1280000" in r.stdout
     for k in ("hip_vector", "hip_merge", "hip_light"):
         assert re.search(r"^\[%-12s\] sum: +0\.000000  avg: +0\.000000$" % k, r.stdout, re.M), r.stdout
+
+
+@pytest.mark.gpu
+def test_vendor_comparison_kinds_in_the_harness(exe):
+    """`rocsparse` / `rocsparse_stream` (host/spmv/rocsparse_cmp.hpp): the place of `cusparse` in the reference's
+    SPMV_KINDS (spmv.h:19), compiled into the harness only when rocSPARSE is there.  Same tables, same delta
+    check against the CPU path; with 64-bit offsets the kind reports and exits (csrmv has 32-bit offsets)."""
+    path = os.path.join(GOLD, "c1_1138_bus_standin.mtx")
+    kinds = ["hip_vector", "rocsparse", "rocsparse_stream"]
+    r = run(exe, path, *kinds, "--iters", "5")
+    if "is NOT SUPPROT" in r.stderr:
+        pytest.skip("harness built without rocSPARSE")
+    assert r.returncode == 0, r.stderr
+    for k in kinds:
+        m = re.search(r"^\[%-12s\] sum: +([0-9.eE+-]+|nan)  avg: +([0-9.eE+-]+|nan)$" % k, r.stdout, re.M)
+        assert m, r.stdout
+        assert float(m.group(2)) < 1e-3
+    r = run(exe, path, "rocsparse", "--offset", "64")
+    assert r.returncode == 1 and "32-bit row offsets" in r.stderr
