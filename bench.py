@@ -93,11 +93,11 @@ def time_steps(plan, m, x, y_local, y_full, cuts, use_dist, steps, sp):
     The exchange of step k runs beside the SpMV of step k+1 (y_local / y_full are pairs of
     buffers; a buffer is reused only after the exchange that read it has finished); every
     exchange completes inside the timed region."""
-    # HIP events bracket the execute on a sample of the timed steps (about 32, evenly spaced): a pair of timing
-    # events costs the stream ~6 us (measured: 184.1 us per step with a pair on every step, 178.8 us with one
-    # on every 6th; the bracketed execute reads 178.7 and 180.6 us) — that belongs to the measurement, not to
-    # the step
-    stride = max(1, steps // 32)
+    # HIP events bracket EVERY timed execute.  A pair costs the stream ~6 us of wall per step (184.1 vs 178.8 us
+    # with a pair on every 6th step), but sampled pairs read the bracketed execute 2-5 % too long (the marker
+    # before it is then not back to back with the one after the previous execute), and the kernel time is
+    # what the roofline fraction is computed from: the rocprofv3 trace agrees with the per-step pairs.
+    stride = 1
     evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
            for i in range(0, steps, stride)}
     pending = [None, None]
