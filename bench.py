@@ -59,6 +59,8 @@ def parse():
                     choices=["s32-band", "s32-rand", "c2-cant", "c3-webgoogle", "c4-nlpkkt", "c5-rmat24"])
     ap.add_argument("--kind", default="auto", choices=("auto",) + KINDS)
     ap.add_argument("--rows-log2", type=int, default=22, help="rows per GPU of the s32 workloads (2^k)")
+    ap.add_argument("--s32-offsets", choices=("i32", "i64"), default="i32", help="offset type of the s32 workloads")
+    ap.add_argument("--s32-values", choices=("f32", "f64"), default="f32", help="value type of the s32 workloads")
     ap.add_argument("--reuse-structure", action="store_true",
                     help="plan flag MI355_PLAN_REUSE_STRUCTURE (merge: keep tile coordinates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -73,6 +75,8 @@ def build_local(sp, args, rank, world, dev):
         n = 1 << args.rows_log2
         hw = 4096 if args.workload == "s32-band" else None
         m = sp.synth.banded_fixed(n, 32, hw, seed=1 + rank, device=dev, row_offset=rank * n, n_cols=world * n,
+                                  val_dtype=torch.float64 if args.s32_values == "f64" else torch.float32,
+                                  off_dtype=torch.int64 if args.s32_offsets == "i64" else torch.int32,
                                   name="S32-band" if hw else "S32-rand")
         cuts = [p * n for p in range(world + 1)]
         return m, cuts

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <new>
+#include <unordered_map>
 
 #include "common.hpp"
 #include "xwindow.hpp"
@@ -174,6 +175,18 @@ __global__ __launch_bounds__(kBlock) void chunk_table_kernel(int32_t n_rows, con
         else lo = mid + 1;
     }
     chunk_row[c] = int32_t(lo & ~int64_t(3));   // multiples of 4 rows keep the y sweep on 16-byte stores
+}
+
+int allow_dynamic_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return MI355_SPMV_OK;
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> allowed;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = allowed[kernel];
+    if (have >= bytes) return MI355_SPMV_OK;
+    MI355_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    have = bytes;
+    return MI355_SPMV_OK;
 }
 
 int long_steps_for(const Plan& p) {
@@ -374,6 +387,28 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
         if (force || (long_chunk && p.window_elems > 0 && p.n_seg < 2 && p.window_from_band)) return;
     }
     shape(kBlock, 32768);
+    // A band too wide for either budget (fp64 halves what 36 KB holds: the S32-band shape in fp64 ran on plain
+    // gathers, 704 us): gfx950 lets a workgroup take more than the default 64 KB of LDS, and two workgroups of
+    // 512 threads with ~78 KB each still fit a CU.  The chunk is then as long as the band leaves room for.
+    if (allow_wide && !force && p.probe_ok && !(p.window_elems > 0 && p.n_seg < 2 && p.window_from_band) &&
+        !getenv("MI355_SPMV_WINDOW") && !getenv("MI355_SPMV_ROWS_PER_CHUNK")) {
+        const int64_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
+        const int64_t band = p.band_hi - p.band_lo + 1;
+        const int64_t pass = int64_t(kWideBlock / p.lanes_per_row) * R;
+        // val (band + rows + 8) + off (rows + 1) + val rows + rows / 8 <= 78 KB
+        int64_t rows = (78 * 1024 - val_bytes * (band + 8) - off_bytes) * 8 / (8 * (2 * val_bytes + off_bytes) + 1);
+        rows = rows / pass * pass;
+        if (rows > kMaxChunkRows) rows = kMaxChunkRows / pass * pass;
+        const int64_t n_chunks = rows > 0 ? (p.n_rows + rows - 1) / rows : 0;
+        if (band > 0 && rows >= 2 * pass && rows >= 256 && n_chunks >= int64_t(kCus) * 4) {
+            const Plan saved = p;
+            p.block_threads = kWideBlock;
+            p.rows_per_chunk = rows;
+            p.window_bytes = int(val_bytes * (band + rows + 8));
+            p.window_elems = pick_window_elems(p, rows);
+            if (!(p.window_elems > 0 && p.n_seg < 2 && p.window_from_band)) p = saved;   // (several bands etc.: keep the 256-thread plan)
+        }
+    }
 }
 
 // Rows per workgroup for which the plan's bands fit the window exactly:

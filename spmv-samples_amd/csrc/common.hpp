@@ -90,6 +90,10 @@ struct Plan {
     char main_kernel[64];
 };
 
+// A launch that asks for more dynamic LDS than the default 64 KB cap must raise the kernel's limit first
+// (gfx950: up to 160 KB per workgroup).  Remembered per kernel, so the call happens once.
+int allow_dynamic_lds(const void* kernel, size_t bytes);
+
 // kernel launchers (one translation unit per kind)
 template <typename off_t, typename val_t>
 int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s);

@@ -124,8 +124,10 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
     case TT:                                                                                                 \
         if (p.window_elems > 0 && p.n_seg >= 2)                                                              \
             hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, R, kMaxSegments, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS); \
-        else if (p.window_elems > 0)                                                                         \
+        else if (p.window_elems > 0) {                                                                       \
+            if (const int st = allow_dynamic_lds((const void*)csr_vector_window_kernel<BLOCK, TT, R, 1, false, off_t, val_t>, lds)) return st; \
             hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, R, 1, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
+        }                                                                                                    \
         else                                                                                                 \
             hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, R, 0, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
         break;

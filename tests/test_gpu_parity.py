@@ -340,6 +340,26 @@ def test_chunks_are_cut_by_weight_only_when_rows_are_uneven(sp, oracle):
     p.destroy()
 
 
+@pytest.mark.parametrize("kind", ["vector", "light"])
+def test_wide_band_fp64_takes_more_than_64_kb_of_lds(sp, oracle, kind):
+    """The S32-band shape in fp64 (band of 8 193 columns = 64 KB of doubles): the window only fits when the
+    workgroup takes more than the default 64 KB of LDS (two 512-thread workgroups of ~78 KB per CU).  Every
+    row against the fp64 oracle bound."""
+    n = 700000
+    m = sp.synth.banded_fixed(n, 32, 4096, seed=3, device=DEV, val_dtype=torch.float64)
+    x = sp.synth.dense_vector(m.n_cols, torch.float64, 9, DEV)
+    p = sp.Plan(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, torch.float64)
+    info = p.info()
+    if not any(k.startswith("MI355_SPMV_") for k in os.environ if k != "MI355_SPMV_LIB"):   # (no forced code path)
+        assert info["block_threads"] == 512 and info["window_elems"] * 8 > 64 * 1024, info
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device=DEV)
+    p.execute(m.Ax, x, y)
+    torch.cuda.synchronize()
+    p.destroy()
+    Ap, Aj, Ax = m.numpy()
+    assert_parity(oracle, Ap, Aj, Ax, x.cpu().numpy(), y.cpu().numpy())
+
+
 # ---- BASELINE-sized inputs ---------------------------------------------------------------------
 
 @pytest.mark.parametrize("kind", KINDS)
