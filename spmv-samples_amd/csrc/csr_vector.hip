@@ -85,8 +85,8 @@ void shape_vector(Plan& p) {
         const int t = atoi(e);
         if (t == 2 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64) p.lanes_per_row = t;
     }
-    // (512-thread workgroups only with 32-bit offsets: the 64-bit-offset kernels need 120-190 VGPRs)
-    shape_chunks(p, R, 1, p.off_type == MI355_OFF_I32);     // workgroup size, rows per chunk, window of x (analyze.hip)
+    // (512-thread workgroups need <= 128 VGPRs: not the fp32 kernels with 64-bit offsets, 180)
+    shape_chunks(p, R, 1, p.off_type == MI355_OFF_I32 || p.val_type == MI355_VAL_F64);   // (analyze.hip)
     p.grid_blocks = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
     if (p.grid_blocks < 1) p.grid_blocks = 1;
     p.n_tiles = p.grid_blocks;
