@@ -400,7 +400,7 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
         rows = rows / pass * pass;
         if (rows > kMaxChunkRows) rows = kMaxChunkRows / pass * pass;
         const int64_t n_chunks = rows > 0 ? (p.n_rows + rows - 1) / rows : 0;
-        if (band > 0 && rows >= 2 * pass && rows >= 256 && n_chunks >= int64_t(kCus) * 4) {
+        if (band > 0 && rows >= pass && rows >= 256 && n_chunks >= int64_t(kCus) * 2) {   // (>= one full round of the chip)
             const Plan saved = p;
             p.block_threads = kWideBlock;
             p.rows_per_chunk = rows;
