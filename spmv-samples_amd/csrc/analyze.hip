@@ -375,6 +375,28 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
             need = (need + 3) & ~int64_t(3);
             if (need < p.window_elems) p.window_elems = int(need);
         }
+        // Whole rounds: with a few chunks per workgroup slot, a last round that is a third full costs a quarter
+        // of the kernel (2^20 rows: 1 024 chunks on 768 slots).  Shrink the chunk so that the count is a multiple
+        // of the slots the plan's LDS and registers leave on the chip.
+        if (!getenv("MI355_SPMV_ROWS_PER_CHUNK") && p.n_seg < 2) {
+            const size_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
+            const size_t lds = chunk_lds_bytes(p.window_elems, int(p.rows_per_chunk), off_bytes, val_bytes) + 1024;
+            int64_t per_cu = int64_t(160 * 1024 / lds);
+            const int64_t reg_bound = block_threads == kWideBlock ? 2 : 4;
+            if (per_cu > reg_bound) per_cu = reg_bound;
+            const int64_t slots = int64_t(kCus) * (per_cu > 0 ? per_cu : 1);
+            const int64_t n_chunks = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
+            const int64_t rounds = (n_chunks + slots - 1) / slots;
+            if (n_chunks > slots / 2 && rounds < 8 && n_chunks % slots != 0) {
+                int64_t r = (int64_t(p.n_rows) + rounds * slots - 1) / (rounds * slots);
+                r = (r + 3) & ~int64_t(3);
+                if (r >= pass && r < p.rows_per_chunk) {
+                    const int64_t shrink = p.rows_per_chunk - r;
+                    p.rows_per_chunk = r;
+                    if (p.window_elems > shrink && p.window_from_band) p.window_elems -= int(shrink & ~int64_t(3));
+                }
+            }
+        }
     };
     const char* force = getenv("MI355_SPMV_BLOCK");
     if (force ? atoi(force) == kWideBlock : allow_wide) {
