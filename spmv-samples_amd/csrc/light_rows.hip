@@ -98,6 +98,36 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock ? 4 : 1)) void light_ro
     scr.alpha = alpha;
     scr.beta = beta;
     scr.long_steps = cmap.long_steps;
+    // the body of one chunk (all threads; ends with the results swept to y)
+    auto run_chunk = [&](int64_t chunk_begin, int64_t chunk_end) {
+        stage_chunk_bounds<off_t, val_t>(scr, chunk_begin, chunk_end, Ap);
+        __syncthreads();      // (also orders the read of s_got before the next dequeue writes it)
+        // the window is staged inside chunk_rows, behind the first group's stream loads
+        if constexpr (NSEG > 1) {
+            auto stage = [&] {
+                return stage_x_segments<val_t>(chunk_begin, chunk_end, n_cols, x, scr.s_x, window_cap, segs);
+            };
+            chunk_rows_any<BLOCK, T, R, true, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
+        } else {
+            auto stage = [&] {
+                return stage_x_window<off_t, val_t>(chunk_begin, chunk_end, n_cols, Ap, Aj, x, scr.s_x, window_cap,
+                                                    s_red, hint);
+            };
+            chunk_rows_any<BLOCK, T, R, NSEG == 1, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
+        }
+    };
+    // No more chunks than workgroups (small matrices): there is nothing to balance — every workgroup takes the
+    // chunk of its index and the counters are not touched.  (The dequeue costs two dependent atomics and a
+    // shard poll per workgroup: 32 vs 14 us on 2^17 rows.)
+    if (cmap.n_chunks <= int64_t(gridDim.x)) {
+        const int64_t chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
+        int64_t chunk_begin, chunk_end;
+        if (chunk < cmap.n_chunks) {
+            cmap.range(chunk, n_rows, chunk_begin, chunk_end);
+            if (chunk_begin < chunk_end) run_chunk(chunk_begin, chunk_end);
+        }
+        return;
+    }
     const int home = blockIdx.x % kXcds;
     unsigned busy = 1u << home;
     for (int visit = 0; visit < kXcds; ++visit) {
@@ -124,21 +154,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock ? 4 : 1)) void light_ro
                 __syncthreads();              // s_got read by all before the next dequeue overwrites it
                 continue;
             }
-            stage_chunk_bounds<off_t, val_t>(scr, chunk_begin, chunk_end, Ap);
-            __syncthreads();      // (also orders this read of s_got before the next dequeue writes it)
-            // the window is staged inside chunk_rows, behind the first group's stream loads
-            if constexpr (NSEG > 1) {
-                auto stage = [&] {
-                    return stage_x_segments<val_t>(chunk_begin, chunk_end, n_cols, x, scr.s_x, window_cap, segs);
-                };
-                chunk_rows_any<BLOCK, T, R, true, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
-            } else {
-                auto stage = [&] {
-                    return stage_x_window<off_t, val_t>(chunk_begin, chunk_end, n_cols, Ap, Aj, x, scr.s_x, window_cap,
-                                                        s_red, hint);
-                };
-                chunk_rows_any<BLOCK, T, R, NSEG == 1, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
-            }
+            run_chunk(chunk_begin, chunk_end);
             __syncthreads();  // every wave is done with the window before it is refilled
         }
         __syncthreads();      // s_got read by all before the next shard's dequeue overwrites it
@@ -195,17 +211,27 @@ template <typename val_t> constexpr int light_rows_in_flight() { return sizeof(v
 #ifndef MI355_TU_F64   // the host-side shape functions live in the fp32 translation unit only
 static int64_t light_resident(const Plan& p, int64_t rows) {
     // persistent grid = what stays resident on a CU: bounded by LDS (160 KB: the chunk's layout + ~1 KB static)
-    // and by registers (5 workgroups of 256 threads, 2 of 512).  Asking for more than fits leaves the surplus
+    // and by registers (3 workgroups of 256 threads, 2 of 512).  Asking for more than fits leaves the surplus
     // workgroups to start when the others have finished everything (4 asked / 3 resident: 207 vs 200 us).
     const char* er = getenv("MI355_LIGHT_BLOCKS_PER_CU");
     if (er && atoi(er) > 0) return int64_t(kCus) * atoi(er);
     const size_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
     const size_t lds = chunk_lds_bytes(p.window_elems, int(rows), off_bytes, val_bytes) + 1024;
     int64_t per_cu = int64_t(160 * 1024 / lds);
-    const int64_t reg_bound = p.block_threads == kWideBlock ? 2 : 5;
+    // registers: the 256-thread kernels take ~150 VGPRs with 32-bit offsets (3 waves per SIMD), ~190 with 64-bit
+    const int64_t reg_bound = p.block_threads == kWideBlock ? 2 : (p.off_type == MI355_OFF_I64 ? 2 : 3);
     if (per_cu > reg_bound) per_cu = reg_bound;
     if (per_cu < 1) per_cu = 1;
     return int64_t(kCus) * per_cu;
+}
+
+// Workgroups to launch: a persistent grid (what stays resident) that dequeues chunks when there are several
+// chunks per workgroup to balance; one workgroup per chunk, taken by index, when there are at most two per slot
+// (the dequeue — two dependent atomics and a poll per workgroup — then costs more than it can balance away).
+static int64_t light_grid(const Plan& p, int64_t n_chunks, int64_t resident) {
+    (void)p;
+    int64_t blocks = n_chunks <= 2 * resident ? n_chunks : resident;
+    return blocks < 1 ? 1 : blocks;
 }
 
 void shape_light(Plan& p) {
@@ -217,11 +243,7 @@ void shape_light(Plan& p) {
     // (512-thread workgroups only with 32-bit offsets: under the 128-VGPR cap the 64-bit kernels spill 80 registers)
     shape_chunks(p, R, ev && atoi(ev) > 0 ? atoi(ev) : 1, p.off_type == MI355_OFF_I32);
     p.n_tiles = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
-    int64_t blocks = p.n_tiles;                     // fewer than resident for small inputs
-    const int64_t resident = light_resident(p, p.rows_per_chunk);
-    if (blocks > resident) blocks = resident;
-    if (blocks < 1) blocks = 1;
-    p.grid_blocks = blocks;
+    p.grid_blocks = light_grid(p, p.n_tiles, light_resident(p, p.rows_per_chunk));
     p.n_kernels = 1;
     snprintf(p.main_kernel, sizeof(p.main_kernel), "light_rows_window_kernel");
 }
@@ -234,9 +256,7 @@ void reshape_light_balanced(Plan& p) {
     p.window_bytes = kWindowBytes;
     p.window_elems = pick_window_elems(p, p.rows_cap);
     if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }
-    const int64_t resident = light_resident(p, p.rows_cap);
-    p.grid_blocks = p.n_chunks < resident ? p.n_chunks : resident;
-    if (p.grid_blocks < 1) p.grid_blocks = 1;
+    p.grid_blocks = light_grid(p, p.n_chunks, light_resident(p, p.rows_cap));
 }
 
 #endif  // MI355_TU_F64
