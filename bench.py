@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--reuse-structure", action="store_true",
                     help="plan flag MI355_PLAN_REUSE_STRUCTURE (merge: keep tile coordinates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cold", action="store_true",
+                    help="write 512 MiB between steps so that nothing of the matrix is left in the 256 MiB Infinity "
+                         "Cache (SURVEY 8d: C2/C3 fit it); the HIP-event kernel time is then the figure to read")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--all-kinds", action="store_true", help="time every kind for K steps (extra field)")
     return ap.parse_args()
@@ -90,6 +93,9 @@ def build_local(sp, args, rank, world, dev):
     return m, cuts
 
 
+_FLUSH = {"buf": None}
+
+
 def time_steps(plan, m, x, y_local, y_full, cuts, use_dist, steps, sp):
     """K steps; returns (wall seconds between the two syncs, mean device ms of one execute).
     use_dist: a process group exists (launched by torch.distributed.run) -> every step ends
@@ -113,6 +119,8 @@ def time_steps(plan, m, x, y_local, y_full, cuts, use_dist, steps, sp):
         k = i & 1
         if pending[k] is not None and not pending[k].done():   # (a finished exchange needs no stream-level wait)
             pending[k].wait()
+        if _FLUSH["buf"] is not None:
+            _FLUSH["buf"].fill_(float(i))      # cold mode: evict the matrix from L2 / Infinity Cache
         ev = evs.get(i)
         if ev:
             ev[0].record()
@@ -213,6 +221,8 @@ def main():
             os.close(saved)
     sp = graft.load_package()
 
+    if args.cold:
+        _FLUSH["buf"] = torch.empty(512 << 18, dtype=torch.float32, device=dev)   # 512 MiB
     m, cuts = build_local(sp, args, rank, world, dev)
     x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, dev)  # same seed on every rank: replicated x
     y_local = [torch.empty(m.n_rows, dtype=m.Ax.dtype, device=dev) for _ in range(2)]
