@@ -15,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <unordered_map>
+#include <utility>
 
 #include "common.hpp"
 #include "xwindow.hpp"
@@ -248,7 +249,69 @@ int decide_balance(Plan& p) {
     return MI355_SPMV_OK;
 }
 
+// ---- giant rows (giant_rows.hpp) ------------------------------------------------------------------
+template <typename off_t>
+__global__ __launch_bounds__(kBlock) void giant_scan_kernel(int32_t n_rows, const off_t* __restrict__ Ap, int cap,
+                                                            long long* out) {   // out[0] = count, then (row, length) pairs
+    for (int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x; r < n_rows; r += int64_t(gridDim.x) * kBlock) {
+        const int64_t len = int64_t(Ap[r + 1]) - int64_t(Ap[r]);
+        if (len > kGiantRow) {
+            const unsigned long long i = atomicAdd(reinterpret_cast<unsigned long long*>(out), 1ull);
+            if (i < (unsigned long long)cap) {
+                out[1 + 2 * i] = r;
+                out[2 + 2 * i] = len;
+            }
+        }
+    }
+}
+
+int find_giant_rows(Plan& p) {
+    p.n_giant = 0;
+    p.n_giant_slices = 0;
+    const char* ev = getenv("MI355_SPMV_GIANT");                 // 0 disables (tuning / tests)
+    if (!p.balanced || (ev && atoi(ev) == 0)) return MI355_SPMV_OK;
+    static_assert(1 + 2 * size_t(kMaxGiantRows) <= kAnalysisWords, "analysis buffer");
+    std::lock_guard<std::mutex> lock(g_analysis_mutex);
+    long long* buf = analysis_buffer();
+    if (!buf) { set_error("find_giant_rows: no device scratch"); return MI355_SPMV_ENOMEM; }
+    hipError_t e = hipMemsetAsync(buf, 0, sizeof(long long), nullptr);
+    if (e == hipSuccess) {
+        const unsigned g = unsigned(std::min<int64_t>((int64_t(p.n_rows) + kBlock - 1) / kBlock, 2048));
+        if (p.off_type == MI355_OFF_I32)
+            hipLaunchKernelGGL((giant_scan_kernel<int32_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
+                               static_cast<const int32_t*>(p.Ap), kMaxGiantRows, buf);
+        else
+            hipLaunchKernelGGL((giant_scan_kernel<int64_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
+                               static_cast<const int64_t*>(p.Ap), kMaxGiantRows, buf);
+        e = hipGetLastError();
+    }
+    long long h[1 + 2 * kMaxGiantRows];
+    if (e == hipSuccess) e = hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost);   // synchronises
+    if (e != hipSuccess) {
+        set_error("find_giant_rows: %s", hipGetErrorString(e));
+        return MI355_SPMV_EHIP;
+    }
+    const long long count = h[0];
+    if (count <= 0 || count > kMaxGiantRows) return MI355_SPMV_OK;   // none, or too many to be "a few dense rows"
+    std::pair<long long, long long> rows[kMaxGiantRows];
+    for (long long i = 0; i < count; ++i) rows[i] = {h[1 + 2 * i], h[2 + 2 * i]};
+    std::sort(rows, rows + count);                                // the device appended them in any order
+    p.giant_slice_first_host[0] = 0;
+    for (long long i = 0; i < count; ++i) {
+        p.giant_row_host[i] = int32_t(rows[i].first);
+        p.giant_slice_first_host[i + 1] = p.giant_slice_first_host[i] + (rows[i].second + kGiantSlice - 1) / kGiantSlice;
+    }
+    p.n_giant = int(count);
+    p.n_giant_slices = p.giant_slice_first_host[count];
+    return MI355_SPMV_OK;
+}
+
 int build_chunk_table(Plan& p) {
+    if (p.n_giant > 0) {
+        MI355_HIP_TRY(hipMemcpy(p.giant_row, p.giant_row_host, sizeof(int32_t) * size_t(p.n_giant), hipMemcpyHostToDevice));
+        MI355_HIP_TRY(hipMemcpy(p.giant_slice_first, p.giant_slice_first_host, sizeof(int64_t) * size_t(p.n_giant + 1),
+                                hipMemcpyHostToDevice));
+    }
     if (!p.balanced) return MI355_SPMV_OK;
     const unsigned g = unsigned((p.n_chunks + 1 + kBlock - 1) / kBlock);
     if (p.off_type == MI355_OFF_I32)

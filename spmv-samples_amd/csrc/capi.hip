@@ -71,6 +71,12 @@ static int plan_alloc_scratch(Plan& p) {
     }
     size_t o_chunk_row = 0;
     if (p.balanced) { o_chunk_row = off; off = align_up(off + sizeof(int32_t) * size_t(p.n_chunks + 1), 256); }
+    size_t o_giant_row = 0, o_giant_first = 0, o_giant_partial = 0;
+    if (p.n_giant > 0) {
+        o_giant_row = off;     off = align_up(off + sizeof(int32_t) * size_t(p.n_giant), 256);
+        o_giant_first = off;   off = align_up(off + sizeof(int64_t) * size_t(p.n_giant + 1), 256);
+        o_giant_partial = off; off = align_up(off + val_bytes * size_t(p.n_giant_slices), 256);
+    }
     p.scratch_bytes = off;
     p.scratch = nullptr;
     if (off) {
@@ -84,6 +90,11 @@ static int plan_alloc_scratch(Plan& p) {
         p.carry_val = base + o_carry_val;
         p.counters = reinterpret_cast<unsigned long long*>(base + o_counters);
         if (p.balanced) p.chunk_row = reinterpret_cast<int32_t*>(base + o_chunk_row);
+        if (p.n_giant > 0) {
+            p.giant_row = reinterpret_cast<int32_t*>(base + o_giant_row);
+            p.giant_slice_first = reinterpret_cast<int64_t*>(base + o_giant_first);
+            p.giant_partial = base + o_giant_partial;
+        }
         if (p.kind == MI355_KIND_LIGHT) {   // zero once; the kernel re-arms the counters at the end of every execute
             MI355_HIP_TRY(hipMemset(p.counters, 0, 128 * size_t(kXcds + 1)));
             MI355_HIP_TRY(hipStreamSynchronize(nullptr));   // the first execute may come on any stream
@@ -208,6 +219,9 @@ int mi355_spmv_plan_create(mi355_spmv_plan** out, int kind, int off_type, int va
         if (st != MI355_SPMV_OK) { delete h; return st; }
         if (kind == MI355_KIND_VECTOR) reshape_vector_balanced(p);
         else reshape_light_balanced(p);
+        const int st2 = find_giant_rows(p);  // balanced plans: rows too long for one workgroup (synchronises)
+        if (st2 != MI355_SPMV_OK) { delete h; return st2; }
+        if (p.n_giant > 0) p.n_kernels = 3;
     }
     int st = plan_alloc_scratch(p);
     if (st == MI355_SPMV_OK) st = build_chunk_table(p);

@@ -13,6 +13,9 @@ namespace mi355 {
 
 constexpr int kWave = 64;            // gfx950 wavefront width
 constexpr int kBlock = 256;          // 4 waves per workgroup
+constexpr int kMaxGiantRows = 256;    // giant rows a plan handles (more: they stay with their workgroup)
+constexpr int64_t kGiantRow = 65536;   // a row beyond this many nonzeros is cut into slices of kGiantSlice
+constexpr int64_t kGiantSlice = 32768;
 constexpr int kWideBlock = 512;      // VECTOR / LIGHT on big uniform matrices: 8 waves, chunks twice as long
 constexpr int kXcds = 8;             // XCDs per MI355X, each with a private L2
 constexpr int kCus = 256;            // compute units per MI355X
@@ -77,6 +80,14 @@ struct Plan {
     int rows_cap;               // rows the LDS layout of a workgroup holds (>= any chunk)
     int64_t bal_k, bal_q;       // a row weighs (its nonzeros + bal_k), a chunk holds <= bal_q of weight
     int32_t* chunk_row;         // [n_chunks + 1], device (balanced plans only)
+    // giant rows (balanced plans): rows beyond kGiantRow nonzeros are cut into slices summed by separate workgroups
+    int n_giant;                // 0 = none
+    int64_t n_giant_slices;
+    int32_t giant_row_host[kMaxGiantRows];
+    int64_t giant_slice_first_host[kMaxGiantRows + 1];
+    int32_t* giant_row;         // [n_giant], device
+    int64_t* giant_slice_first; // [n_giant + 1], device
+    void* giant_partial;        // [n_giant_slices] of value type, device
     // scratch
     void* scratch;
     size_t scratch_bytes;
@@ -109,6 +120,7 @@ void shape_chunks(Plan& p, int rows_in_flight, int64_t chunk_div, bool allow_wid
 int long_steps_for(const Plan& p);   // steps of its vector after which a row is left to the long-row pass
 int decide_balance(Plan& p);       // VECTOR / LIGHT, after shape_*: uniform or nnz-balanced chunks
 int build_chunk_table(Plan& p);    // after the scratch is allocated
+int find_giant_rows(Plan& p);      // balanced plans: rows beyond kGiantRow nonzeros (synchronises)
 void shape_vector(Plan& p);
 void shape_merge(Plan& p);
 void shape_light(Plan& p);

@@ -18,6 +18,7 @@
 
 #include "common.hpp"
 #include "row_dot.hpp"
+#include "giant_rows.hpp"
 #include "xwindow.hpp"
 
 namespace mi355 {
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock ? 4 : 1)) void csr_vect
     scr.alpha = alpha;
     scr.beta = beta;
     scr.long_steps = cmap.long_steps;
+    scr.giant_len = cmap.giant_len;
     const unsigned chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
     int64_t rb, re;
     cmap.range(chunk, n_rows, rb, re);
@@ -115,7 +117,7 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
     const dim3 grid((unsigned)p.grid_blocks), block(BLOCK);
     const off_t nnz = (off_t)p.nnz;
     const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(off_t), sizeof(val_t));
-    const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, long_steps_for(p)};
+    const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, long_steps_for(p), p.n_giant > 0 ? kGiantRow : int64_t(0)};
     SegmentPlan segs;
     segs.n = p.n_seg;
     for (int i = 0; i < kMaxSegments; ++i) { segs.lo[i] = p.seg_lo[i]; segs.hi[i] = p.seg_hi[i]; }
@@ -137,7 +139,7 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
         else
             hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, 2, R, 0, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);
         MI355_HIP_TRY(hipGetLastError());
-        return MI355_SPMV_OK;
+        return launch_giant_rows<off_t, val_t>(p, Ap, Ax, x, y, s);   // (rows too long for one workgroup, if any)
     }
     switch (p.lanes_per_row) {
         MI355_VEC_CASE(2)

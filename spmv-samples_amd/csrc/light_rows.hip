@@ -39,6 +39,7 @@
 
 #include "common.hpp"
 #include "row_dot.hpp"
+#include "giant_rows.hpp"
 #include "xwindow.hpp"
 
 namespace mi355 {
@@ -83,9 +84,10 @@ __device__ __forceinline__ void light_leave(unsigned long long* __restrict__ cou
 }
 
 // (512 threads: two workgroups per CU need 4 waves per SIMD, i.e. <= 128 VGPRs — the persistent loop's
-// state would otherwise take 151 and leave one workgroup per CU)
+// state would otherwise take 151 and leave one workgroup per CU; 256 threads: three workgroups per CU need
+// 3 waves per SIMD, <= 168 VGPRs — the per-chunk-width and 64-bit-offset variants would take 177-220)
 template <int BLOCK, int T, int R, int NSEG, bool ADAPT, typename off_t, typename val_t>
-__global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock ? 4 : 1)) void light_rows_window_kernel(
+__global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock ? 4 : 3)) void light_rows_window_kernel(
     int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
     unsigned long long* __restrict__ counters, ChunkMap cmap, int32_t window_cap, BandHint hint,
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock ? 4 : 1)) void light_ro
     scr.alpha = alpha;
     scr.beta = beta;
     scr.long_steps = cmap.long_steps;
+    scr.giant_len = cmap.giant_len;
     // the body of one chunk (all threads; ends with the results swept to y)
     auto run_chunk = [&](int64_t chunk_begin, int64_t chunk_end) {
         stage_chunk_bounds<off_t, val_t>(scr, chunk_begin, chunk_end, Ap);
@@ -218,8 +221,8 @@ static int64_t light_resident(const Plan& p, int64_t rows) {
     const size_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
     const size_t lds = chunk_lds_bytes(p.window_elems, int(rows), off_bytes, val_bytes) + 1024;
     int64_t per_cu = int64_t(160 * 1024 / lds);
-    // registers: the 256-thread kernels take ~150 VGPRs with 32-bit offsets (3 waves per SIMD), ~190 with 64-bit
-    const int64_t reg_bound = p.block_threads == kWideBlock ? 2 : (p.off_type == MI355_OFF_I64 ? 2 : 3);
+    // registers: the kernels are bounded to 3 waves per SIMD (256 threads) / 4 (512 threads), see the kernel
+    const int64_t reg_bound = p.block_threads == kWideBlock ? 2 : 3;
     if (per_cu > reg_bound) per_cu = reg_bound;
     if (per_cu < 1) per_cu = 1;
     return int64_t(kCus) * per_cu;
@@ -268,7 +271,7 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
     const dim3 grid((unsigned)p.grid_blocks), block(BLOCK);
     const off_t nnz = (off_t)p.nnz;
-    const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, long_steps_for(p)};
+    const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, long_steps_for(p), p.n_giant > 0 ? kGiantRow : int64_t(0)};
     const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(off_t), sizeof(val_t));
     SegmentPlan segs;
     segs.n = p.n_seg;
@@ -291,7 +294,7 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
         else
             hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, 2, R, 0, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);
         MI355_HIP_TRY(hipGetLastError());
-        return MI355_SPMV_OK;
+        return launch_giant_rows<off_t, val_t>(p, Ap, Ax, x, y, s);   // (rows too long for one workgroup, if any)
     }
     switch (p.lanes_per_row) {
         MI355_LIGHT_CASE(2)

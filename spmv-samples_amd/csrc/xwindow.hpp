@@ -261,6 +261,7 @@ struct ChunkMap {
     int32_t rows_cap;         // rows the workgroup's LDS layout holds
     int64_t n_chunks;
     int32_t long_steps;       // a row is "long" (left to the second pass) beyond this many steps of its vector
+    int64_t giant_len;        // > 0: a row beyond this many nonzeros is left to the giant-row kernels (giant_rows.hpp)
     __device__ __forceinline__ void range(int64_t c, int32_t n_rows, int64_t& rb, int64_t& re) const {
         if (table) {
             rb = table[c];
@@ -286,6 +287,7 @@ struct ChunkScratch {
     unsigned* long_map;   // rows / 32 + 1 : one bit per row, set = long row, summed in the second pass
     val_t alpha, beta;    // y = alpha * (A x) + beta * y   (1, 0 unless mi355_spmv_plan_set_alpha_beta)
     int long_steps = kLongSteps;
+    int64_t giant_len = 0;   // > 0: rows longer than this are summed by giant_rows.hpp, this workgroup stores 0 for them
     __device__ ChunkScratch(unsigned char* base, int window_elems, int rows) {
         s_x = reinterpret_cast<val_t*>(base);
         base += lds_align16(size_t(window_elems) * sizeof(val_t));
@@ -542,6 +544,10 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
                 const int local = (w << 5) + bpos;
                 const off_t start = scr.s_b[local], end = scr.s_b[local + 1];
                 if (end - start <= off_t(kHugeRow)) continue;            // uniform over the workgroup
+                if (scr.giant_len > 0 && int64_t(end - start) > scr.giant_len) {   // split across workgroups elsewhere
+                    if (threadIdx.x == 0) scr.s_y[local] = val_t(0);
+                    continue;
+                }
                 // the main loop's pipeline again: R slabs of BLOCK x 4 nonzeros in flight, the next
                 // R issued before the current ones are consumed, branch-free clamped addresses (a slab past
                 // the row re-reads the row's first line and is masked by hi_v)

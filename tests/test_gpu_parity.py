@@ -340,6 +340,46 @@ def test_chunks_are_cut_by_weight_only_when_rows_are_uneven(sp, oracle):
     p.destroy()
 
 
+@pytest.mark.parametrize("off", [np.int32, np.int64])
+def test_giant_rows_are_split_across_workgroups(sp, oracle, off):
+    """Rows of more than 65 536 nonzeros in a plan with weight-cut chunks: the chunk kernel leaves them to the
+    slice kernels (giant_rows.hpp), which add the slices' partial sums in slice order.  Integer-valued data:
+    bit-exact, every repetition; alpha/beta included."""
+    rng = np.random.RandomState(61)
+    n, n_cols = 30000, 20000
+    lens = rng.randint(0, 9, size=n).astype(np.int64)
+    lens[5] = 300001                                     # 10 slices, the last one short
+    lens[29999] = 70000                                  # the last row of the matrix
+    lens[12345] = 65536                                  # exactly at the threshold: NOT giant
+    Ap = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=Ap[1:])
+    nnz = int(Ap[-1])
+    Aj = rng.randint(0, n_cols, size=nnz).astype(np.int32)
+    Ax = rng.randint(-2, 3, size=nnz).astype(np.float32)
+    x = rng.randint(-2, 3, size=n_cols).astype(np.float32)
+    want = oracle.spmv_serial(Ap.astype(np.int32), Aj, Ax, x)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    dAp, dAj, dAx, dx = d(Ap.astype(off)), d(Aj), d(Ax), d(x)
+    for kind in ("vector", "light"):
+        p = sp.Plan(kind, n, n_cols, nnz, dAp, dAj, torch.float32)
+        info = p.info()
+        if not any(k.startswith("MI355_SPMV_") for k in os.environ if k != "MI355_SPMV_LIB"):
+            assert info["balanced_chunks"] == 1 and info["n_kernels"] == 3, info
+        y = torch.empty(n, device=DEV)
+        for rep in range(20):
+            y.fill_(float("nan"))
+            p.execute(dAx, dx, y)
+            torch.cuda.synchronize()
+            assert np.array_equal(y.cpu().numpy(), want), (kind, rep)
+        y0 = rng.randint(-3, 4, size=n).astype(np.float32)
+        y.copy_(torch.from_numpy(y0))
+        p.set_alpha_beta(2.0, -1.0)
+        p.execute(dAx, dx, y)
+        torch.cuda.synchronize()
+        assert np.array_equal(y.cpu().numpy(), 2.0 * want - y0), kind
+        p.destroy()
+
+
 @pytest.mark.parametrize("kind", ["vector", "light"])
 def test_wide_band_fp64_takes_more_than_64_kb_of_lds(sp, oracle, kind):
     """The S32-band shape in fp64 (band of 8 193 columns = 64 KB of doubles): the window only fits when the
