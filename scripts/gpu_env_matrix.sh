@@ -3,7 +3,7 @@
 # lengths and search widths, weight-cut chunks on/off, workgroup size, the 4-byte fallback kernel, long-row pass)
 mkdir -p gpurun_out
 rc=0
-for env in "MI355_SPMV_WINDOW=1" "MI355_SPMV_WINDOW=0" "MI355_SPMV_WINDOW_FROM_BAND=0" "MI355_SPMV_SEGMENTS=0" "MI355_MERGE_TPS=1" "MI355_MERGE_TPS=5" "MI355_MERGE_SEARCH_LANES=1" "MI355_MERGE_SEARCH_LANES=4" "MI355_SPMV_BALANCE=1" "MI355_SPMV_BALANCE=0" "MI355_SPMV_BLOCK=512" "MI355_SPMV_BLOCK=256" "MI355_SPMV_PLAIN=1" "MI355_SPMV_LONG_STEPS=1" "MI355_MERGE_BLOCK=512"; do
+for env in "MI355_SPMV_WINDOW=1" "MI355_SPMV_WINDOW=0" "MI355_SPMV_WINDOW_FROM_BAND=0" "MI355_SPMV_SEGMENTS=0" "MI355_MERGE_TPS=1" "MI355_MERGE_TPS=5" "MI355_MERGE_SEARCH_LANES=1" "MI355_MERGE_SEARCH_LANES=4" "MI355_SPMV_BALANCE=1" "MI355_SPMV_BALANCE=0" "MI355_SPMV_BLOCK=512" "MI355_SPMV_BLOCK=256" "MI355_SPMV_PLAIN=1" "MI355_SPMV_LONG_STEPS=1" "MI355_MERGE_BLOCK=512" "MI355_SPMV_GIANT=0"; do
   env $env timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/pt_env.log 2>&1
   r=$?
   echo "$env : exit $r : $(tail -1 gpurun_out/pt_env.log)"
