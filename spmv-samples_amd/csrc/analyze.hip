@@ -472,6 +472,8 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
         if (force || (long_chunk && p.window_elems > 0 && p.n_seg < 2 && p.window_from_band)) return;
     }
     shape(kBlock, 32768);
+    // (several bands with two 512-thread workgroups of 78 KB per CU and 1 664-row chunks: measured 722 vs 700 us on the
+    // C4 stand-in — the 256-thread plan stays)
     // A band too wide for either budget (fp64 halves what 36 KB holds: the S32-band shape in fp64 ran on plain
     // gathers, 704 us): gfx950 lets a workgroup take more than the default 64 KB of LDS, and two workgroups of
     // 512 threads with ~78 KB each still fit a CU.  The chunk is then as long as the band leaves room for.

@@ -124,8 +124,10 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
 #define MI355_VEC_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, cmap, (int32_t)p.window_elems, hint, segs, (val_t)p.alpha, (val_t)p.beta
 #define MI355_VEC_CASE(TT)                                                                                   \
     case TT:                                                                                                 \
-        if (p.window_elems > 0 && p.n_seg >= 2)                                                              \
+        if (p.window_elems > 0 && p.n_seg >= 2) {                                                            \
+            if (const int st = allow_dynamic_lds((const void*)csr_vector_window_kernel<BLOCK, TT, R, kMaxSegments, false, off_t, val_t>, lds)) return st; \
             hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, R, kMaxSegments, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS); \
+        }                                                                                                    \
         else if (p.window_elems > 0) {                                                                       \
             if (const int st = allow_dynamic_lds((const void*)csr_vector_window_kernel<BLOCK, TT, R, 1, false, off_t, val_t>, lds)) return st; \
             hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, R, 1, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \

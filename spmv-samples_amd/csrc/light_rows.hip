@@ -279,8 +279,10 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
 #define MI355_LIGHT_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, p.counters, cmap, (int32_t)p.window_elems, hint, segs, (val_t)p.alpha, (val_t)p.beta
 #define MI355_LIGHT_CASE(TT)                                                                                   \
     case TT:                                                                                                   \
-        if (p.window_elems > 0 && p.n_seg >= 2)                                                                \
+        if (p.window_elems > 0 && p.n_seg >= 2) {                                                              \
+            if (const int st = allow_dynamic_lds((const void*)light_rows_window_kernel<BLOCK, TT, R, kMaxSegments, false, off_t, val_t>, lds)) return st; \
             hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, TT, R, kMaxSegments, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS); \
+        }                                                                                                      \
         else if (p.window_elems > 0) {                                                                         \
             if (const int st = allow_dynamic_lds((const void*)light_rows_window_kernel<BLOCK, TT, R, 1, false, off_t, val_t>, lds)) return st; \
             hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, TT, R, 1, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
