@@ -252,10 +252,10 @@ int decide_balance(Plan& p) {
 // ---- giant rows (giant_rows.hpp) ------------------------------------------------------------------
 template <typename off_t>
 __global__ __launch_bounds__(kBlock) void giant_scan_kernel(int32_t n_rows, const off_t* __restrict__ Ap, int cap,
-                                                            long long* out) {   // out[0] = count, then (row, length) pairs
+                                                            int64_t giant_len, long long* out) {   // out[0] = count, then (row, length) pairs
     for (int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x; r < n_rows; r += int64_t(gridDim.x) * kBlock) {
         const int64_t len = int64_t(Ap[r + 1]) - int64_t(Ap[r]);
-        if (len > kGiantRow) {
+        if (len > giant_len) {
             const unsigned long long i = atomicAdd(reinterpret_cast<unsigned long long*>(out), 1ull);
             if (i < (unsigned long long)cap) {
                 out[1 + 2 * i] = r;
@@ -270,6 +270,8 @@ int find_giant_rows(Plan& p) {
     p.n_giant_slices = 0;
     const char* ev = getenv("MI355_SPMV_GIANT");                 // 0 disables (tuning / tests)
     if (!p.balanced || (ev && atoi(ev) == 0)) return MI355_SPMV_OK;
+    static const int64_t forced_len = [] { const char* e = getenv("MI355_SPMV_GIANT_ROW"); return e ? atoll(e) : 0ll; }();
+    p.giant_len = forced_len >= 4096 ? forced_len : kGiantRow;
     static_assert(1 + 2 * size_t(kMaxGiantRows) <= kAnalysisWords, "analysis buffer");
     std::lock_guard<std::mutex> lock(g_analysis_mutex);
     long long* buf = analysis_buffer();
@@ -279,10 +281,10 @@ int find_giant_rows(Plan& p) {
         const unsigned g = unsigned(std::min<int64_t>((int64_t(p.n_rows) + kBlock - 1) / kBlock, 2048));
         if (p.off_type == MI355_OFF_I32)
             hipLaunchKernelGGL((giant_scan_kernel<int32_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
-                               static_cast<const int32_t*>(p.Ap), kMaxGiantRows, buf);
+                               static_cast<const int32_t*>(p.Ap), kMaxGiantRows, p.giant_len, buf);
         else
             hipLaunchKernelGGL((giant_scan_kernel<int64_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
-                               static_cast<const int64_t*>(p.Ap), kMaxGiantRows, buf);
+                               static_cast<const int64_t*>(p.Ap), kMaxGiantRows, p.giant_len, buf);
         e = hipGetLastError();
     }
     long long h[1 + 2 * kMaxGiantRows];

@@ -82,6 +82,7 @@ struct Plan {
     int32_t* chunk_row;         // [n_chunks + 1], device (balanced plans only)
     // giant rows (balanced plans): rows beyond kGiantRow nonzeros are cut into slices summed by separate workgroups
     int n_giant;                // 0 = none
+    int64_t giant_len;          // rows beyond this many nonzeros are giant (kGiantRow, or MI355_SPMV_GIANT_ROW)
     int64_t n_giant_slices;
     int32_t giant_row_host[kMaxGiantRows];
     int64_t giant_slice_first_host[kMaxGiantRows + 1];

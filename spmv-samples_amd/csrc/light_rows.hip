@@ -271,7 +271,7 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
     const dim3 grid((unsigned)p.grid_blocks), block(BLOCK);
     const off_t nnz = (off_t)p.nnz;
-    const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, long_steps_for(p), p.n_giant > 0 ? kGiantRow : int64_t(0)};
+    const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, long_steps_for(p), p.n_giant > 0 ? p.giant_len : int64_t(0)};
     const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(off_t), sizeof(val_t));
     SegmentPlan segs;
     segs.n = p.n_seg;
