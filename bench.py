@@ -6,9 +6,16 @@
 
 A step = one SpMV  y = A x  through the C ABI (mi355_spmv_plan_execute: every kernel of
 the kind runs every step; the plan only holds scratch and launch shapes), inputs
-resident in HBM.  N > 1: one process per GPU, the matrix is row-sharded (each rank
-holds 2^22 rows of a banded matrix with N*2^22 rows: weak scaling), x is replicated
-and the step ends with the allgatherv of the y slices over RCCL.
+resident in HBM.  N > 1: one process per GPU — `python bench.py --gpus N` starts its N
+rank processes itself (fresh children, before anything here touches a GPU), or the
+driver starts them with torch.distributed.run — the matrix is row-sharded (each rank
+holds 2^22 rows of a banded matrix with N*2^22 rows: weak scaling; --workload c5-rmat24
+cuts ONE R-MAT-24 matrix into N nnz-balanced row blocks: strong scaling), x is
+replicated and every step ends with the allgatherv of the y slices over RCCL, made by the
+library itself (mi355_spmv_dist_*: grouped in-place ncclBroadcasts on a communication
+stream, each GPU's rows in sub-blocks so that a slice travels while the next is computed;
+SURVEY.md §8(e)).  torch.distributed (gloo) only carries the control plane: the 128-byte
+RCCL id, the barriers and the max-over-ranks of the timing.
 
 Default workload = the north-star target named in BASELINE.json / SURVEY.md §8(d):
 S32-band, 2^22 rows, exactly 32 nnz/row inside a +-4096 band, fp32 values, 32-bit
@@ -69,75 +76,138 @@ def parse():
                          "Cache (SURVEY 8d: C2/C3 fit it); the HIP-event kernel time is then the figure to read")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--all-kinds", action="store_true", help="time every kind for K steps (extra field)")
+    ap.add_argument("--sub-blocks", type=int, default=0,
+                    help="row blocks per GPU in the multi-GPU path (0 = 4 when N > 1, else 1)")
     return ap.parse_args()
 
 
-def build_local(sp, args, rank, world, dev):
-    """This rank's row block (global column ids) + the replicated x."""
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N rank processes here (fresh
+    children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; this parent never initialises a GPU),
+    pass rank 0's JSON line through and exit with the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(max(abs(c) for c in codes))
+
+
+def build_local(sp, args, rank, world, dev, sub_blocks):
+    """This rank's row block as a 16-byte-aligned view (spmv-samples_amd/dist.py block_view) + what
+    mi355_spmv_dist_create_rank needs: the global cut lists of all world * sub_blocks blocks and, when ONE
+    matrix is cut (c5), the whole matrix's plan shape so that the blocks sum every row as one GPU would.
+    Returns (local Csr whose Ap[0] is the block's phase, cuts dict)."""
+    parts = world * sub_blocks
     if args.workload in ("s32-band", "s32-rand"):
+        # weak scaling: every rank generates its own 2^k rows of a banded matrix with world * 2^k rows; the
+        # blocks are statistically alike, every rank can write down everybody's cuts (32 nonzeros per row)
         n = 1 << args.rows_log2
         hw = 4096 if args.workload == "s32-band" else None
         m = sp.synth.banded_fixed(n, 32, hw, seed=1 + rank, device=dev, row_offset=rank * n, n_cols=world * n,
                                   val_dtype=torch.float64 if args.s32_values == "f64" else torch.float32,
                                   off_dtype=torch.int64 if args.s32_offsets == "i64" else torch.int32,
                                   name="S32-band" if hw else "S32-rand")
-        cuts = [p * n for p in range(world + 1)]
-        return m, cuts
+        sub = [(n * s // sub_blocks) & ~3 for s in range(sub_blocks)]
+        rows = [r * n + o for r in range(world) for o in sub] + [world * n]
+        return m, {"rows": rows, "chunks": None, "nnz": [32 * r for r in rows], "shape": None, "kind_shape": {}}
     full = sp.synth.workload(args.workload, dev)
-    if world == 1:
-        return full, [0, full.n_rows]
-    cuts = sp.dist.partition_rows(full.Ap, world)
-    a, j, v = sp.dist.shard_csr(full.Ap, full.Aj, full.Ax, cuts[rank], cuts[rank + 1])
-    m = sp.synth.Csr(cuts[rank + 1] - cuts[rank], full.n_cols, int(j.numel()), a, j, v, full.name, full.meta)
-    del full
-    return m, cuts
+    if world == 1 and sub_blocks == 1:
+        return full, {"rows": [0, full.n_rows], "chunks": None, "nnz": [0, full.nnz], "shape": None, "kind_shape": {}}
+    # strong scaling: ONE matrix, cut on the chunk boundaries of its own one-GPU plan (per kind)
+    kind_shape = {}
+    for k in (KINDS if args.kind == "auto" or args.all_kinds else (args.kind,)):
+        whole = sp.Plan(k, full.n_rows, full.n_cols, full.nnz, full.Ap, full.Aj, full.Ax.dtype)
+        kind_shape[k] = (whole.shape(),) + whole.partition(parts)
+        whole.destroy()
+    return full, {"rows": None, "chunks": None, "nnz": None, "shape": None, "kind_shape": kind_shape}
+
+
+class Runner:
+    """One kind on this rank: a plain plan (single GPU, one block) or the library's multi-GPU object."""
+
+    def __init__(self, sp, kind, m, cuts, rank, world, sub_blocks, unique_id, flags, use_dist):
+        self.kind, self.m, self.use_dist = kind, m, use_dist
+        if not use_dist:
+            self.plan = sp.Plan(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype, flags)
+            self.Ax, self.n_rows_global, self.n_rows_local, self.nnz_local = m.Ax, m.n_rows, m.n_rows, m.nnz
+            return
+        if kind in cuts["kind_shape"]:       # one matrix cut into blocks (c5): this rank keeps its view only
+            shape, rows, chunks, nnzs = cuts["kind_shape"][kind]
+            first = rank * sub_blocks
+            r0, r1 = rows[first], rows[first + sub_blocks]
+            Ap_l, Aj_l, Ax_l, _ = sp.dist.block_view(m.Ap, m.Aj, m.Ax, r0, r1)
+        else:                                # every rank generated its own block (s32): Ap[0] == 0 already
+            shape, rows, chunks, nnzs = None, cuts["rows"], cuts["chunks"], cuts["nnz"]
+            r0, r1 = rows[rank * sub_blocks], rows[(rank + 1) * sub_blocks]
+            Ap_l, Aj_l, Ax_l = m.Ap, m.Aj, m.Ax
+        self.rows = rows
+        self.Ax = Ax_l
+        self.n_rows_global, self.n_rows_local = rows[-1], r1 - r0
+        self.nnz_local = nnzs[(rank + 1) * sub_blocks] - nnzs[rank * sub_blocks]
+        self.plan = sp.DistPlan.rank(kind, rank, world, unique_id, sub_blocks, rows, chunks, nnzs, shape, m.n_cols,
+                                     r1 - r0, int(Ap_l[-1].item()), Ap_l, Aj_l, m.Ax.dtype, flags)
+
+    def execute(self, x, y):
+        self.plan.execute(self.Ax, x, y)
+
+    def info(self):
+        return self.plan.info()        # (multi-GPU object: its first block's launch shape)
+
+    def destroy(self):
+        self.plan.destroy()
 
 
 _FLUSH = {"buf": None}
 
 
-def time_steps(plan, m, x, y_local, y_full, cuts, use_dist, steps, sp):
-    """K steps; returns (wall seconds between the two syncs, mean device ms of one execute).
-    use_dist: a process group exists (launched by torch.distributed.run) -> every step ends
-    with the allgatherv of the y slices, and the timed region is bracketed by barriers.
-    The exchange of step k runs beside the SpMV of step k+1 (y_local / y_full are pairs of
-    buffers; a buffer is reused only after the exchange that read it has finished); every
-    exchange completes inside the timed region."""
+def time_steps(run, x, y, use_dist, steps):
+    """K steps; returns (wall seconds between the two syncs, list of device ms of every execute).
+    A step of the multi-GPU path is complete when this GPU holds the WHOLE y (the library makes the
+    caller's stream wait for its communication stream), so the HIP events bracket SpMV + exchange there."""
     # HIP events bracket EVERY timed execute.  A pair costs the stream ~6 us of wall per step (184.1 vs 178.8 us
     # with a pair on every 6th step), but sampled pairs read the bracketed execute 2-5 % too long (the marker
     # before it is then not back to back with the one after the previous execute), and the kernel time is
     # what the roofline fraction is computed from: the rocprofv3 trace agrees with the per-step pairs.
-    stride = 1
-    evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for i in range(0, steps, stride)}
-    pending = [None, None]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        k = i & 1
-        if pending[k] is not None and not pending[k].done():   # (a finished exchange needs no stream-level wait)
-            pending[k].wait()
         if _FLUSH["buf"] is not None:
             _FLUSH["buf"].fill_(float(i))      # cold mode: evict the matrix from L2 / Infinity Cache
-        ev = evs.get(i)
-        if ev:
-            ev[0].record()
-        plan.execute(m.Ax, x, y_local[k])
-        if ev:
-            ev[1].record()
-        if use_dist:
-            pending[k] = sp.dist.allgatherv(y_local[k], y_full[k], cuts, async_op=True)
-    for w in pending:
-        if w is not None:
-            w.wait()
+        evs[i][0].record()
+        run.execute(x, y)
+        evs[i][1].record()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     wall = time.perf_counter() - t0
-    dev_ms = float(np.mean([a.elapsed_time(b) for a, b in evs.values()]))
-    return wall, dev_ms
+    return wall, [a.elapsed_time(b) for a, b in evs]
+
+
+def one_shot_ms(sp, kind, m, x, y, reps=5):
+    """The reference's per-call life cycle (SURVEY §8(d) "also reported as one-shot time"): plan create
+    (structure probe, scratch) + execute + synchronise + destroy through the one-shot entry point, host
+    clock, median of `reps` after one warm-up."""
+    ts = []
+    for i in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sp.spmv(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax, x, y)   # (synchronises the stream itself)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts[1:]))
 
 
 def cpu_baseline(m, x, budget_s):
@@ -176,18 +246,20 @@ def cpu_baseline(m, x, budget_s):
 
 
 def read_traffic(kernel, algorithmic_bytes):
-    """HBM bytes per launch of `kernel` from the committed PMC summaries (profiles/traffic_latest.json),
-    only when a summary was taken on THIS configuration (same kernel, same algorithmic bytes)."""
+    """(HBM bytes per launch, source) of `kernel` from the committed PMC summaries (profiles/traffic_latest.json):
+    a rocprofv3 --pmc pass cannot run inside this process, so the figure is a RECORDED one — quoted only when
+    a summary was taken on THIS configuration (same kernel, same algorithmic bytes), with its source."""
     p = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(p) as f:
             entries = json.load(f)["entries"]
         for e in entries:
             if e["kernel"] == kernel and int(e["algorithmic_bytes"]) == int(algorithmic_bytes):
-                return e["hbm_bytes_per_launch"]
+                return e["hbm_bytes_per_launch"], "recorded: %s (%s)" % (e.get("source", "profiles/traffic_latest.json"),
+                                                                        e.get("commit", "commit not recorded"))
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -195,77 +267,94 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # by torch.distributed.run or by spawn_ranks
+    if not launched and args.gpus > 1:
+        spawn_ranks(args.gpus)                                          # (does not return)
+    if launched:
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # launched by torch.distributed.run (RANK set): one process per GPU over RCCL, also for N = 1
-    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    # one process per GPU (RANK set), also for N = 1: the library's multi-GPU object, control plane over gloo
+    use_dist = launched
+    sub_blocks = args.sub_blocks if args.sub_blocks > 0 else (4 if world > 1 else 1)
+    sp = graft.load_package()
+    unique_id = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL prints a version banner on stdout when the communicator comes up; stdout is
-        # reserved for the one JSON line, so route fd 1 to stderr until the first collective is done
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
-    sp = graft.load_package()
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if world > 1:
+            # RCCL prints a version banner on stdout when a communicator comes up; stdout is reserved for
+            # the one JSON line, so fd 1 points at stderr while communicators are made (Runner, below)
+            box = [sp.DistPlan.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            unique_id = box[0]
 
     if args.cold:
         _FLUSH["buf"] = torch.empty(512 << 18, dtype=torch.float32, device=dev)   # 512 MiB
-    m, cuts = build_local(sp, args, rank, world, dev)
+    m, cuts = build_local(sp, args, rank, world, dev, sub_blocks) if use_dist else build_local(sp, args, 0, 1, dev, 1)
     x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, dev)  # same seed on every rank: replicated x
-    y_local = [torch.empty(m.n_rows, dtype=m.Ax.dtype, device=dev) for _ in range(2)]
-    y_full = [torch.empty(cuts[-1], dtype=m.Ax.dtype, device=dev) for _ in range(2)] if use_dist else y_local
     flags = sp.capi.PLAN_REUSE_STRUCTURE if args.reuse_structure else 0
-    plans = {k: sp.Plan(k, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype, flags)
-             for k in (KINDS if args.kind == "auto" or args.all_kinds else (args.kind,))}
+    kinds = KINDS if args.kind == "auto" or args.all_kinds else (args.kind,)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        # (a fresh 128-byte id per communicator: one per kind when several kinds are timed)
+        runs = {}
+        for k in kinds:
+            uid = unique_id
+            if use_dist and world > 1 and runs:
+                box = [sp.DistPlan.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
+            runs[k] = Runner(sp, k, m, cuts, rank, world, sub_blocks, uid, flags, use_dist)
+        n_rows_global = next(iter(runs.values())).n_rows_global
+        y = torch.empty(n_rows_global, dtype=m.Ax.dtype, device=dev)
 
-    # warm-up; with --kind auto the warm-up also picks the kind (outside the timed region)
-    probe = {}
-    for k, p in plans.items():
-        time_steps(p, m, x, y_local, y_full, cuts, use_dist, max(args.warmup, 1), sp)   # warm-up proper
-    for k, p in plans.items():
-        _, ms = time_steps(p, m, x, y_local, y_full, cuts, use_dist, max(args.warmup, 30), sp)
-        probe[k] = ms
+        # warm-up; with --kind auto the warm-up also picks the kind (outside the timed region)
+        probe = {}
+        for k, r in runs.items():
+            time_steps(r, x, y, use_dist, max(args.warmup, 1))   # warm-up proper
+        for k, r in runs.items():
+            _, ms = time_steps(r, x, y, use_dist, max(args.warmup, 30))
+            probe[k] = float(np.mean(ms))
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
     kind = args.kind
     if kind == "auto":
-        best = torch.tensor([probe[k] for k in KINDS], device=dev)
+        best = torch.tensor([probe[k] for k in KINDS], dtype=torch.float64)
         if use_dist:
             dist.all_reduce(best, op=dist.ReduceOp.MAX)
         kind = KINDS[int(torch.argmin(best).item())]
-    plan = plans[kind]
+    run = runs[kind]
 
-    wall, dev_ms = time_steps(plan, m, x, y_local, y_full, cuts, use_dist, args.steps, sp)
-    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
-    nnz_all = torch.tensor([m.nnz], dtype=torch.float64, device=dev)
+    wall, dev_list = time_steps(run, x, y, use_dist, args.steps)
+    dev_ms = float(np.mean(dev_list))
+    tmax = torch.tensor([wall], dtype=torch.float64)
+    nnz_all = torch.tensor([float(run.nnz_local)], dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nnz_all, op=dist.ReduceOp.SUM)
     wall = float(tmax.item())
     total_nnz = float(nnz_all.item())
 
+    v, o = m.Ax.element_size(), m.Ap.element_size()
+    bytes_alg = run.nnz_local * (v + 4) + (run.n_rows_local + 1) * o + run.n_rows_local * v + m.n_cols * v
     others = {}
     if args.all_kinds:
-        for k, p in plans.items():
-            _, ms = time_steps(p, m, x, y_local, y_full, cuts, use_dist, args.steps, sp)
-            others[k] = {"kernel_ms": ms, "gflops": 2.0 * m.nnz / ms / 1e6,
-                         "gbps": m.algorithmic_bytes() / ms / 1e6}
+        for k, r in runs.items():
+            _, ms = time_steps(r, x, y, use_dist, args.steps)
+            ms = float(np.mean(ms))
+            others[k] = {"kernel_ms": ms, "gflops": 2.0 * r.nnz_local / ms / 1e6, "gbps": bytes_alg / ms / 1e6}
 
     if rank == 0:
-        info = plan.info()
-        bytes_alg = m.algorithmic_bytes()
+        strong = bool(cuts["kind_shape"])
+        info = run.info()
         achieved = bytes_alg / (dev_ms * 1e-3) / 1e9
+        traffic, traffic_source = read_traffic(info["main_kernel"], bytes_alg)
         out = {
             # BASELINE.json's metric, verbatim; `value` is its GFLOP/s part, the achieved HBM GB/s part
             # is `achieved_hbm_gbps` / `roofline.achieved`
@@ -274,31 +363,44 @@ def main():
             "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32" if m.Ax.dtype == torch.float32 else "f64",
             "data": "synthetic",
-            "config": {"workload": "%s: %d rows/GPU x %d GPU, %d nnz/GPU, %s offsets, seeded"
-                                   % (m.name, m.n_rows, world, m.nnz, "i32" if m.Ap.dtype == torch.int32 else "i64"),
+            "config": {"workload": ("%s: %d rows, %d nnz cut into %d nnz-balanced row blocks (%d per GPU), %s offsets, seeded"
+                                    % (m.name, m.n_rows, m.nnz, world * sub_blocks, sub_blocks,
+                                       "i32" if m.Ap.dtype == torch.int32 else "i64")) if strong else
+                                   ("%s: %d rows/GPU x %d GPU, %d nnz/GPU, %s offsets, seeded"
+                                    % (m.name, run.n_rows_local, world, run.nnz_local,
+                                       "i32" if m.Ap.dtype == torch.int32 else "i64")),
                        "kind": kind, "lanes_per_row": info["lanes_per_row"], "grid_blocks": info["grid_blocks"],
-                       "kernels_per_step": info["n_kernels"], "x_window_elems": info["window_elems"], "x_window_segments": info["window_segments"], "reuse_structure": bool(args.reuse_structure),
-                       "parallelism": ("row-block x%d, x replicated, allgatherv(y) over RCCL overlapped with the next "
-                                       "step's SpMV" % world) if use_dist else "single GPU"},
+                       "kernels_per_step": info["n_kernels"], "x_window_elems": info["window_elems"],
+                       "x_window_segments": info["window_segments"], "reuse_structure": bool(args.reuse_structure),
+                       "knobs": info["knobs"],
+                       "parallelism": ("%d GPU x %d row blocks, x replicated, allgatherv(y) = grouped in-place ncclBroadcast "
+                                       "per sub-block on a communication stream (mi355_spmv_dist_*)" % (world, sub_blocks))
+                                      if use_dist else "single GPU"},
             "achieved_hbm_gbps": achieved,
-            # per-GPU SpMV alone (device time of the execute) vs the whole step incl. the exchange
-            "compute_only": {"ms": dev_ms, "gflops_per_gpu": 2.0 * m.nnz / dev_ms / 1e6,
+            # this GPU's step by HIP events: the SpMV alone on one GPU; SpMV + exchange when N > 1
+            "compute_only": {"ms": dev_ms, "gflops_per_gpu": 2.0 * run.nnz_local / dev_ms / 1e6,
                              "step_ms_incl_exchange": wall / args.steps * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": read_traffic(info["main_kernel"], bytes_alg),
-                         "kernel": info["main_kernel"], "kernel_ms": dev_ms, "algorithmic_bytes": bytes_alg},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": info["main_kernel"], "kernel_ms": dev_ms,
+                         "kernel_ms_min": float(np.min(dev_list)), "kernel_ms_median": float(np.median(dev_list)),
+                         "algorithmic_bytes": bytes_alg,
+                         "timed": "HIP events around every execute of the timed region" +
+                                  (" (SpMV + exchange of this GPU)" if use_dist and world > 1 else "")},
             "warmup_probe_ms": probe,
         }
         if others:
             out["all_kinds"] = others
-        if world == 1 and not args.no_cpu_baseline:
+        if not use_dist:
+            out["one_shot_ms"] = one_shot_ms(sp, kind, m, x, y)
+        if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, x, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    for p in plans.values():
-        p.destroy()
+    for r in runs.values():
+        r.destroy()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

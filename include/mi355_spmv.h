@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI355_SPMV_VERSION 100 /* 0.1.0 */
+#define MI355_SPMV_VERSION 200 /* 0.2.0 */
 
 /* status codes */
 enum {
@@ -167,8 +167,105 @@ typedef struct mi355_spmv_plan_info {
                                  row) because equal-row chunks were uneven, 0 = equal-row chunks           */
     int32_t rows_cap;         /* VECTOR, LIGHT: most rows a chunk can hold                                 */
     int64_t n_chunks;         /* VECTOR, LIGHT: row chunks                                                 */
+    char knobs[160];          /* the MI355_* tuning variables that were set when the plan was created, "NAME=value ..." */
 } mi355_spmv_plan_info;
 int mi355_spmv_plan_get_info(const mi355_spmv_plan* plan, mi355_spmv_plan_info* info);
+
+/* ---- row-block plans --------------------------------------------------------
+ * rows are independent, so a matrix is cut into contiguous row blocks (one or more per GPU)
+ * and each block is an ordinary CSR SpMV.  For the concatenated y to equal the one-GPU y BIT FOR BIT with
+ * the row-local kinds (VECTOR, LIGHT), a block must sum every row exactly as the whole matrix's plan does:
+ * same lanes per row, same workgroup size, same chunks (hence the same per-chunk vector width and the same
+ * window of x), same long-row and giant-row treatment, same 16-byte phase of every row start.  So:
+ *   mi355_spmv_plan_get_shape   the launch-shape decisions of a plan, as plain data (can be sent to other
+ *                               processes);
+ *   mi355_spmv_plan_partition   nnz-balanced cut points that fall on the plan's chunk boundaries;
+ *   mi355_spmv_plan_create_block  a plan for rows [row_begin, row_begin + n_rows) of that matrix which inherits
+ *                               the shape.  Its arrays are a 16-byte-aligned VIEW of the whole CSR:
+ *                               Aj / Ax start at element (Ap_whole[row_begin] & ~3) and Ap[i] =
+ *                               Ap_whole[row_begin + i] - (Ap_whole[row_begin] & ~3), so Ap[0] is 0..3 (the
+ *                               "phase") and nnz is the END offset Ap[n_rows].  No copy of Aj / Ax is needed on
+ *                               the device that holds the whole matrix.
+ * MERGE blocks take the same arrays but are shaped on their own (tile boundaries move with the cut anyway;
+ * results stay inside the parity bound); shape may then be NULL.                              */
+typedef struct mi355_spmv_plan_shape {
+    int32_t struct_bytes;             /* sizeof(mi355_spmv_plan_shape) of the library that filled it */
+    int32_t kind, off_type, val_type;
+    int32_t n_rows, n_cols;           /* the whole matrix */
+    int64_t nnz;
+    int32_t lanes_per_row, elems_per_lane, block_threads;
+    int32_t balanced_chunks, rows_cap, giant_rows_enabled;
+    int64_t rows_per_chunk, n_chunks, bal_k, bal_q, giant_len;
+    int32_t window_elems, window_bytes, window_from_band, window_segments, probe_ok, long_steps;
+    int64_t band_lo, band_hi, seg_lo[4], seg_hi[4];
+} mi355_spmv_plan_shape;
+int mi355_spmv_plan_get_shape(const mi355_spmv_plan* plan, mi355_spmv_plan_shape* shape);
+/* parts + 1 entries each: row_cuts[p] = first row of block p, chunk_cuts[p] = its first chunk in the plan's
+ * numbering (0 for MERGE), nnz_cuts[p] = Ap[row_cuts[p]].  Cuts are multiples of 4 rows (or n_rows), chosen so
+ * that nnz_cuts[p] ~ p * nnz / parts.  Reads Ap on the device (synchronises).                              */
+int mi355_spmv_plan_partition(const mi355_spmv_plan* plan, int parts, int64_t* row_cuts, int64_t* chunk_cuts,
+                              int64_t* nnz_cuts);
+int mi355_spmv_plan_create_block(mi355_spmv_plan** plan, int kind, int off_type, int val_type,
+                                 const mi355_spmv_plan_shape* whole, int64_t row_begin, int64_t chunk_begin,
+                                 int64_t n_chunks, int64_t nnz_begin_whole,
+                                 int32_t n_rows, int32_t n_cols, int64_t nnz_end, const void* Ap,
+                                 const int32_t* Aj, int flags);
+
+/* ---- multi-GPU: row blocks, x replicated, allgatherv(y) over RCCL/xGMI -------------------------------
+ * The reference is single-device (main.cu:53, common.cuh:8); the north star adds one node of 8 GPUs:
+ * contiguous nnz-balanced row blocks, x replicated, the y slices concatenated on every GPU.  RCCL has no
+ * allgatherv: block p is broadcast from its owner into its displacement of every GPU's y (grouped
+ * ncclBroadcast calls on a dedicated stream).  Each GPU's rows are cut into `sub_blocks` blocks so that the
+ * slice of block s travels while block s + 1 is being computed.  RCCL (librccl.so.1) is loaded on first use,
+ * and only when more than one GPU takes part: libmi355spmv.so itself links the HIP runtime only.
+ *
+ * LOCAL mode — one process drives all the GPUs (the reference's single-threaded harness, `--ngpu N`):
+ *   create_local   Ap / Aj of the WHOLE matrix on the current device ("home"); blocks are dealt to
+ *                  `devices` in order (parts = n_devices * sub_blocks); remote blocks get copies of
+ *                  their slice of Ap / Aj, the home device's blocks are views.
+ *   scatter_values / replicate_x   refresh the remote copies of Ax / x from home-device arrays
+ *   execute(d, Ax, x, y, stream)   Ax / x / y on the home device; Ax or x may be NULL = "unchanged since the
+ *                  last scatter / replicate"; non-NULL pointers are scattered / replicated first (the drop-in
+ *                  semantics of SpMV(kind, ...), which hands over home-device arrays on every call).  y (n_rows)
+ *                  receives the full result on the home device; every other GPU holds it too (device_y).
+ * RANK mode — one process per GPU (torch.distributed / MPI style launch):
+ *   unique_id      128 bytes made by ONE rank, distributed by the caller's own means
+ *   create_rank    this rank's blocks (parts_per_rank consecutive blocks of the global cut list), its slice
+ *                  of the structure; `whole` = the shape of the whole matrix's plan when bitwise identity
+ *                  with a one-GPU run is wanted (NULL: every block is shaped on its own)
+ *   execute(d, Ax, x, y, stream)   Ax = this rank's values (view described above), x = this GPU's copy of
+ *                  x, y = this GPU's full-length y.
+ * With one GPU (n_devices == 1 / world == 1) no communicator is made and execute is the blocks' plain
+ * executes on the caller's stream.                                                                          */
+typedef struct mi355_spmv_dist mi355_spmv_dist;
+int mi355_spmv_dist_create_local(mi355_spmv_dist** dist, int kind, int off_type, int val_type,
+                                 int32_t n_rows, int32_t n_cols, int64_t nnz, const void* Ap,
+                                 const int32_t* Aj, int n_devices, const int* devices, int sub_blocks,
+                                 int flags);
+int mi355_spmv_dist_unique_id(void* id128);
+int mi355_spmv_dist_create_rank(mi355_spmv_dist** dist, int kind, int off_type, int val_type,
+                                int rank, int world, const void* id128, int parts_per_rank,
+                                const int64_t* row_cuts, const int64_t* chunk_cuts, const int64_t* nnz_cuts,
+                                const mi355_spmv_plan_shape* whole, int32_t n_cols,
+                                int32_t n_rows_local, int64_t nnz_end_local, const void* Ap_local,
+                                const int32_t* Aj_local, int flags);
+int mi355_spmv_dist_scatter_values(mi355_spmv_dist* dist, const void* Ax, void* stream);
+int mi355_spmv_dist_replicate_x(mi355_spmv_dist* dist, const void* x, void* stream);
+int mi355_spmv_dist_execute(mi355_spmv_dist* dist, const void* Ax, const void* x, void* y, void* stream);
+int mi355_spmv_dist_set_alpha_beta(mi355_spmv_dist* dist, double alpha, double beta);
+/* number of blocks, and the global cut rows (parts + 1 entries)                */
+int mi355_spmv_dist_parts(const mi355_spmv_dist* dist);
+int mi355_spmv_dist_cuts(const mi355_spmv_dist* dist, int64_t* row_cuts);
+/* launch shape of this process's block `part` (0 .. devices_of_this_process * sub_blocks - 1)             */
+int mi355_spmv_dist_part_info(const mi355_spmv_dist* dist, int part, mi355_spmv_plan_info* info);
+/* LOCAL mode: GPU `device_index`'s (position in `devices`) copies of y / x      */
+void* mi355_spmv_dist_device_y(mi355_spmv_dist* dist, int device_index);
+void* mi355_spmv_dist_device_x(mi355_spmv_dist* dist, int device_index);
+int mi355_spmv_dist_destroy(mi355_spmv_dist* dist);
+
+/* Re-read the MI355_* tuning variables from the environment (they are otherwise parsed once per process;
+ * plans keep the values they were created under and report the non-default ones in plan_info.knobs). */
+int mi355_spmv_knobs_reload(void);
 
 /* MERGE only, for parity tests: copy the tile start coordinates the search
  * kernel produced by the last execute to HOST arrays of n_tiles+1 entries

@@ -79,13 +79,18 @@ class Oracle:
             C.c_int32(n), _p(Ap), _p(Aj), _p(Ax), _p(x), _p(y), C.c_int(n_threads))
         return y
 
-    def spmv_ref64(self, Ap, Aj, Ax, x):
-        """(fp64 serial sum, sum of |a*x|) per row: the two terms of the parity bound."""
+    def spmv_ref64(self, Ap, Aj, Ax, x, n_threads=1):
+        """(fp64 serial sum, sum of |a*x|) per row: the two terms of the parity bound.
+        n_threads > 1 splits the ROWS over threads; each row is the same serial sum."""
         n = self._check(Ap, Aj, Ax, x)
         o, v = suffix(Ap, Ax)
         y64 = np.empty(n, dtype=np.float64)
         ya = np.empty(n, dtype=np.float64)
-        getattr(self.lib, f"oracle_spmv_ref64_{o}_{v}")(C.c_int32(n), _p(Ap), _p(Aj), _p(Ax), _p(x), _p(y64), _p(ya))
+        if n_threads > 1:
+            getattr(self.lib, f"oracle_spmv_ref64_parallel_{o}_{v}")(
+                C.c_int32(n), _p(Ap), _p(Aj), _p(Ax), _p(x), _p(y64), _p(ya), C.c_int(n_threads))
+        else:
+            getattr(self.lib, f"oracle_spmv_ref64_{o}_{v}")(C.c_int32(n), _p(Ap), _p(Aj), _p(Ax), _p(x), _p(y64), _p(ya))
         return y64, ya
 
     def spmv_vector_order(self, Ap, Aj, Ax, x, T, aligned_when_longer_than=-1):

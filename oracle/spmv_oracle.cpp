@@ -89,6 +89,35 @@ void spmv_ref64(int32_t n_rows, const off_t* Ap, const int32_t* Aj,
     }
 }
 
+// spmv_ref64 over rows split into nnz-balanced contiguous ranges, one thread each: every row is still
+// the serial fp64 sum above, so the two outputs are identical to the 1-thread call (used by the
+// BASELINE-sized parity tests, where the serial pass over 2-3 * 10^8 random gathers takes a while).
+template <typename off_t, typename val_t>
+void spmv_ref64_parallel(int32_t n_rows, const off_t* Ap, const int32_t* Aj, const val_t* Ax, const val_t* x,
+                         double* y64, double* yabs, int n_threads) {
+    if (n_threads <= 1 || n_rows < n_threads) {
+        spmv_ref64<off_t, val_t>(n_rows, Ap, Aj, Ax, x, y64, yabs);
+        return;
+    }
+    const off_t nnz = Ap[n_rows];
+    std::vector<int32_t> cut(n_threads + 1);
+    cut[0] = 0;
+    cut[n_threads] = n_rows;
+    for (int t = 1; t < n_threads; ++t) {
+        off_t target = off_t((long double)nnz * t / n_threads);
+        cut[t] = int32_t(std::lower_bound(Ap, Ap + n_rows, target) - Ap);
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; ++t) {
+        pool.emplace_back([=] {
+            const int32_t r0 = cut[t], r1 = cut[t + 1];
+            spmv_ref64<off_t, val_t>(r1 - r0, Ap + r0, Aj, Ax, x, y64 + r0, yabs + r0);
+        });
+    }
+    for (auto& th : pool) th.join();
+}
+
 // All-core variant of (1) for the reported CPU baseline (BASELINE.md §2b ii):
 // static, nnz-balanced contiguous row chunks, each chunk running the serial
 // loop above, so every y[row] is bit-identical to the 1-core result.
@@ -514,6 +543,11 @@ extern "C" {
     void oracle_spmv_ref64_##SUF(int32_t n_rows, const OFF* Ap, const int32_t* Aj,             \
                                  const VAL* Ax, const VAL* x, double* y64, double* yabs) {     \
         spmv_ref64<OFF, VAL>(n_rows, Ap, Aj, Ax, x, y64, yabs);                                \
+    }                                                                                          \
+    void oracle_spmv_ref64_parallel_##SUF(int32_t n_rows, const OFF* Ap, const int32_t* Aj,    \
+                                          const VAL* Ax, const VAL* x, double* y64,            \
+                                          double* yabs, int n_threads) {                       \
+        spmv_ref64_parallel<OFF, VAL>(n_rows, Ap, Aj, Ax, x, y64, yabs, n_threads);            \
     }                                                                                          \
     void oracle_spmv_vector_order_##SUF(int32_t n_rows, const OFF* Ap, const int32_t* Aj,      \
                                         const VAL* Ax, const VAL* x, VAL* y, int T,            \

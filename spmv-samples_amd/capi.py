@@ -30,6 +30,11 @@ EXPORTS = (
     + ["mi355_spmv_plan_create", "mi355_spmv_plan_execute", "mi355_spmv_plan_destroy",
        "mi355_spmv_plan_get_info", "mi355_spmv_stream_synchronize", "mi355_spmv_plan_merge_coords", "mi355_spmv_version",
        "mi355_spmv_status_string", "mi355_spmv_last_error", "mi355_spmv_device_count"]
+    + ["mi355_spmv_plan_get_shape", "mi355_spmv_plan_partition", "mi355_spmv_plan_create_block",
+       "mi355_spmv_knobs_reload"]
+    + ["mi355_spmv_dist_" + n for n in ("create_local", "unique_id", "create_rank", "scatter_values", "replicate_x",
+                                        "execute", "set_alpha_beta", "parts", "cuts", "part_info", "device_y", "device_x",
+                                        "destroy")]
 )
 
 
@@ -39,12 +44,27 @@ class PlanInfo(C.Structure):
                 ("grid_blocks", C.c_int64), ("tile_items", C.c_int64), ("n_tiles", C.c_int64),
                 ("rows_per_chunk", C.c_int64), ("scratch_bytes", C.c_int64), ("n_kernels", C.c_int32),
                 ("window_elems", C.c_int32), ("window_segments", C.c_int32), ("main_kernel", C.c_char * 64),
-                ("balanced_chunks", C.c_int32), ("rows_cap", C.c_int32), ("n_chunks", C.c_int64)]
+                ("balanced_chunks", C.c_int32), ("rows_cap", C.c_int32), ("n_chunks", C.c_int64),
+                ("knobs", C.c_char * 160)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
         d["main_kernel"] = d["main_kernel"].decode()
+        d["knobs"] = d["knobs"].decode()
         return d
+
+
+class PlanShape(C.Structure):
+    """mi355_spmv_plan_shape: the launch-shape decisions of a plan as plain data (picklable via bytes(shape))."""
+    _fields_ = [("struct_bytes", C.c_int32), ("kind", C.c_int32), ("off_type", C.c_int32), ("val_type", C.c_int32),
+                ("n_rows", C.c_int32), ("n_cols", C.c_int32), ("nnz", C.c_int64),
+                ("lanes_per_row", C.c_int32), ("elems_per_lane", C.c_int32), ("block_threads", C.c_int32),
+                ("balanced_chunks", C.c_int32), ("rows_cap", C.c_int32), ("giant_rows_enabled", C.c_int32),
+                ("rows_per_chunk", C.c_int64), ("n_chunks", C.c_int64), ("bal_k", C.c_int64), ("bal_q", C.c_int64),
+                ("giant_len", C.c_int64),
+                ("window_elems", C.c_int32), ("window_bytes", C.c_int32), ("window_from_band", C.c_int32),
+                ("window_segments", C.c_int32), ("probe_ok", C.c_int32), ("long_steps", C.c_int32),
+                ("band_lo", C.c_int64), ("band_hi", C.c_int64), ("seg_lo", C.c_int64 * 4), ("seg_hi", C.c_int64 * 4)]
 
 
 _lib = None
@@ -69,6 +89,30 @@ def lib():
         L.mi355_spmv_plan_set_alpha_beta.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.mi355_spmv_plan_get_info.argtypes = [C.c_void_p, C.POINTER(PlanInfo)]
         L.mi355_spmv_plan_merge_coords.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi355_spmv_plan_get_shape.argtypes = [C.c_void_p, C.POINTER(PlanShape)]
+        L.mi355_spmv_plan_partition.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi355_spmv_plan_create_block.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        L.mi355_spmv_dist_create_local.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int32,
+                                                   C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                   C.c_int, C.c_int]
+        L.mi355_spmv_dist_unique_id.argtypes = [C.c_void_p]
+        L.mi355_spmv_dist_create_rank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        L.mi355_spmv_dist_scatter_values.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi355_spmv_dist_replicate_x.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi355_spmv_dist_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi355_spmv_dist_set_alpha_beta.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.mi355_spmv_dist_parts.argtypes = [C.c_void_p]
+        L.mi355_spmv_dist_cuts.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi355_spmv_dist_part_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(PlanInfo)]
+        L.mi355_spmv_dist_device_y.argtypes = [C.c_void_p, C.c_int]
+        L.mi355_spmv_dist_device_y.restype = C.c_void_p
+        L.mi355_spmv_dist_device_x.argtypes = [C.c_void_p, C.c_int]
+        L.mi355_spmv_dist_device_x.restype = C.c_void_p
+        L.mi355_spmv_dist_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -177,6 +221,39 @@ class Plan:
         _check(lib().mi355_spmv_plan_get_info(self._h, C.byref(pi)), "mi355_spmv_plan_get_info")
         return pi.as_dict()
 
+    def shape(self):
+        """The plan's launch-shape decisions (mi355_spmv_plan_get_shape)."""
+        sh = PlanShape()
+        _check(lib().mi355_spmv_plan_get_shape(self._h, C.byref(sh)), "mi355_spmv_plan_get_shape")
+        return sh
+
+    def partition(self, parts):
+        """nnz-balanced cuts on the plan's chunk boundaries: (row_cuts, chunk_cuts, nnz_cuts), parts + 1 each."""
+        import numpy as np
+        arrs = [np.zeros(parts + 1, dtype=np.int64) for _ in range(3)]
+        _check(lib().mi355_spmv_plan_partition(self._h, parts, *[a.ctypes.data_as(C.c_void_p) for a in arrs]),
+               "mi355_spmv_plan_partition")
+        return tuple(a.tolist() for a in arrs)
+
+    @classmethod
+    def block(cls, kind, whole_shape, row_begin, chunk_begin, n_chunks, nnz_begin_whole, n_rows, n_cols, nnz_end,
+              Ap, Aj, val_dtype, flags=0):
+        """Plan for a row block given as a 16-byte-aligned VIEW of the whole CSR (Ap[0] in 0..3, nnz_end =
+        Ap[n_rows]); inherits `whole_shape` (a PlanShape, or None) — mi355_spmv_plan_create_block."""
+        kind = LABELS.get(kind, kind)
+        _require_device(Ap, Aj)
+        self = cls.__new__(cls)
+        self.kind, self.n_rows, self.n_cols, self.nnz = kind, n_rows, n_cols, nnz_end
+        self.Ap, self.Aj, self.val_dtype = Ap, Aj, val_dtype
+        self._h = C.c_void_p()
+        st = lib().mi355_spmv_plan_create_block(
+            C.byref(self._h), KINDS[kind], OFF_TYPES[Ap.dtype][0], VAL_TYPES[val_dtype][0],
+            C.cast(C.byref(whole_shape), C.c_void_p) if whole_shape is not None else None,
+            row_begin, chunk_begin, n_chunks, nnz_begin_whole, n_rows, n_cols, nnz_end,
+            C.c_void_p(Ap.data_ptr()), C.c_void_p(Aj.data_ptr()), flags)
+        _check(st, "mi355_spmv_plan_create_block")
+        return self
+
     def merge_coords(self):
         import numpy as np
         n = self.info()["n_tiles"] + 1
@@ -189,6 +266,125 @@ class Plan:
     def destroy(self):
         if self._h:
             lib().mi355_spmv_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class DistPlan:
+    """mi355_spmv_dist_*: row blocks over the GPUs of a node, x replicated, allgatherv(y) over RCCL.
+
+    DistPlan.local(...)  one process drives `devices` (the whole structure lives on the current device)
+    DistPlan.rank(...)   one process per GPU: this rank's slice + the global cut lists + a 128-byte id
+    """
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self._keep = ()
+
+    @classmethod
+    def local(cls, kind, n_rows, n_cols, nnz, Ap, Aj, val_dtype, parts=None, devices=None, sub_blocks=None, flags=0):
+        kind = LABELS.get(kind, kind)
+        _require_device(Ap, Aj)
+        devices = list(devices) if devices is not None else [Ap.device.index or 0]
+        if sub_blocks is None:
+            sub_blocks = (parts // len(devices)) if parts else 1
+        if parts is not None and parts != sub_blocks * len(devices):
+            raise ValueError("parts must be len(devices) * sub_blocks")
+        self = cls()
+        self.kind, self.n_rows, self.n_cols, self.nnz, self.val_dtype = kind, n_rows, n_cols, nnz, val_dtype
+        self._keep = (Ap, Aj)
+        devs = (C.c_int * len(devices))(*devices)
+        with torch.cuda.device(Ap.device):
+            st = lib().mi355_spmv_dist_create_local(
+                C.byref(self._h), KINDS[kind], OFF_TYPES[Ap.dtype][0], VAL_TYPES[val_dtype][0], n_rows, n_cols, nnz,
+                C.c_void_p(Ap.data_ptr()), C.c_void_p(Aj.data_ptr()), len(devices), C.cast(devs, C.c_void_p),
+                sub_blocks, flags)
+        _check(st, "mi355_spmv_dist_create_local")
+        return self
+
+    @staticmethod
+    def unique_id():
+        """128 bytes from ONE rank; hand them to every rank by your own means."""
+        buf = (C.c_char * 128)()
+        _check(lib().mi355_spmv_dist_unique_id(C.cast(buf, C.c_void_p)), "mi355_spmv_dist_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def rank(cls, kind, rank, world, unique_id, parts_per_rank, row_cuts, chunk_cuts, nnz_cuts, whole_shape,
+             n_cols, n_rows_local, nnz_end_local, Ap_local, Aj_local, val_dtype, flags=0):
+        import numpy as np
+        kind = LABELS.get(kind, kind)
+        _require_device(Ap_local, Aj_local)
+        self = cls()
+        self.kind, self.n_rows, self.n_cols, self.val_dtype = kind, int(row_cuts[-1]), n_cols, val_dtype
+        self.nnz = int(nnz_cuts[-1]) - int(nnz_cuts[0])
+        self._keep = (Ap_local, Aj_local)
+        rc = np.ascontiguousarray(row_cuts, dtype=np.int64)
+        cc = np.ascontiguousarray(chunk_cuts if chunk_cuts is not None else [0] * len(row_cuts), dtype=np.int64)
+        nc = np.ascontiguousarray(nnz_cuts, dtype=np.int64)
+        idbuf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        with torch.cuda.device(Ap_local.device):
+            st = lib().mi355_spmv_dist_create_rank(
+                C.byref(self._h), KINDS[kind], OFF_TYPES[Ap_local.dtype][0], VAL_TYPES[val_dtype][0], rank, world,
+                C.cast(idbuf, C.c_void_p) if idbuf is not None else None, parts_per_rank,
+                rc.ctypes.data_as(C.c_void_p), cc.ctypes.data_as(C.c_void_p), nc.ctypes.data_as(C.c_void_p),
+                C.cast(C.byref(whole_shape), C.c_void_p) if whole_shape is not None else None,
+                n_cols, n_rows_local, nnz_end_local, C.c_void_p(Ap_local.data_ptr()), C.c_void_p(Aj_local.data_ptr()),
+                flags)
+        _check(st, "mi355_spmv_dist_create_rank")
+        return self
+
+    def cuts(self):
+        import numpy as np
+        n = lib().mi355_spmv_dist_parts(self._h)
+        a = np.zeros(n + 1, dtype=np.int64)
+        _check(lib().mi355_spmv_dist_cuts(self._h, a.ctypes.data_as(C.c_void_p)), "mi355_spmv_dist_cuts")
+        return a.tolist()
+
+    def info(self, part=0):
+        """Launch shape of this process's block `part`."""
+        pi = PlanInfo()
+        _check(lib().mi355_spmv_dist_part_info(self._h, part, C.byref(pi)), "mi355_spmv_dist_part_info")
+        return pi.as_dict()
+
+    def scatter_values(self, Ax, stream=None):
+        _require_device(Ax)
+        _check(lib().mi355_spmv_dist_scatter_values(self._h, C.c_void_p(Ax.data_ptr()), _stream_ptr(stream)),
+               "mi355_spmv_dist_scatter_values")
+
+    def replicate_x(self, x, stream=None):
+        _require_device(x)
+        _check(lib().mi355_spmv_dist_replicate_x(self._h, C.c_void_p(x.data_ptr()), _stream_ptr(stream)),
+               "mi355_spmv_dist_replicate_x")
+
+    def execute(self, Ax, x, y, stream=None):
+        """Asynchronous on `stream`.  LOCAL: home-device Ax / x (None = unchanged since scatter_values /
+        replicate_x) and the full y; RANK: this rank's values view, its x, its full-length y."""
+        for t in (Ax, x, y):
+            if t is not None:
+                _require_device(t)
+                if t.dtype != self.val_dtype:
+                    raise TypeError("value type differs from the plan's")
+        if y.numel() < self.n_rows:
+            raise ValueError("y is shorter than the matrix has rows")
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        with torch.cuda.device(y.device):
+            st = lib().mi355_spmv_dist_execute(self._h, p(Ax), p(x), p(y), _stream_ptr(stream))
+        _check(st, "mi355_spmv_dist_execute")
+        return y
+
+    def set_alpha_beta(self, alpha, beta):
+        _check(lib().mi355_spmv_dist_set_alpha_beta(self._h, C.c_double(alpha), C.c_double(beta)),
+               "mi355_spmv_dist_set_alpha_beta")
+
+    def destroy(self):
+        if self._h:
+            lib().mi355_spmv_dist_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

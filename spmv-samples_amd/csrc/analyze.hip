@@ -24,6 +24,57 @@ namespace mi355 {
 
 constexpr int kProbePerRow = 32;   // (column - row) samples per probed row
 
+// ---- knobs --------------------------------------------------------------------------------------
+static std::mutex g_knobs_mutex;
+static Knobs g_knobs;
+static bool g_knobs_ready = false;
+
+static void parse_knobs(Knobs& k) {
+    k = Knobs();
+    size_t used = 0;
+    auto note = [&](const char* name, const char* v) {
+        const int w = snprintf(k.text + used, sizeof(k.text) - used, "%s%s=%s", used ? " " : "", name, v);
+        if (w > 0) used = std::min(sizeof(k.text) - 1, used + size_t(w));
+    };
+    auto geti = [&](const char* name, int& dst) {
+        if (const char* v = getenv(name)) { dst = atoi(v); note(name, v); }
+    };
+    auto getl = [&](const char* name, int64_t& dst) {
+        if (const char* v = getenv(name)) { dst = atoll(v); note(name, v); }
+    };
+    geti("MI355_SPMV_LANES", k.lanes);
+    geti("MI355_SPMV_BLOCK", k.block);
+    getl("MI355_SPMV_ROWS_PER_CHUNK", k.rows_per_chunk);
+    geti("MI355_SPMV_WINDOW", k.window);
+    geti("MI355_SPMV_WINDOW_FROM_BAND", k.window_from_band);
+    geti("MI355_SPMV_SEGMENTS", k.segments);
+    geti("MI355_SPMV_BALANCE", k.balance);
+    geti("MI355_SPMV_LONG_STEPS", k.long_steps);
+    geti("MI355_SPMV_GIANT", k.giant);
+    getl("MI355_SPMV_GIANT_ROW", k.giant_row);
+    geti("MI355_SPMV_PLAIN", k.plain);
+    geti("MI355_LIGHT_BLOCKS_PER_CU", k.light_blocks_per_cu);
+    geti("MI355_LIGHT_CHUNK_DIV", k.light_chunk_div);
+    geti("MI355_MERGE_BLOCK", k.merge_block);
+    geti("MI355_MERGE_TPS", k.merge_tps);
+    geti("MI355_MERGE_SEARCH_LANES", k.merge_search_lanes);
+    geti("MI355_MERGE_FUSED", k.merge_fused);
+    if (k.window > 1) k.window = 1;
+    if (k.balance > 1) k.balance = 1;
+}
+
+const Knobs& knobs() {
+    std::lock_guard<std::mutex> lock(g_knobs_mutex);
+    if (!g_knobs_ready) { parse_knobs(g_knobs); g_knobs_ready = true; }
+    return g_knobs;
+}
+
+void knobs_reload() {
+    std::lock_guard<std::mutex> lock(g_knobs_mutex);
+    parse_knobs(g_knobs);
+    g_knobs_ready = true;
+}
+
 template <typename off_t>
 __global__ __launch_bounds__(kBlock) void probe_kernel(int32_t n_rows, const off_t* __restrict__ Ap,
                                                        const int32_t* __restrict__ Aj, long long* out) {
@@ -161,14 +212,18 @@ __global__ __launch_bounds__(kBlock) void chunk_max_kernel(int32_t n_rows, const
 template <typename off_t>
 __global__ __launch_bounds__(kBlock) void chunk_table_kernel(int32_t n_rows, const off_t* __restrict__ Ap, int64_t k,
                                                              int64_t q, int64_t n_chunks,
-                                                             int32_t* __restrict__ chunk_row) {
+                                                             int32_t* __restrict__ chunk_row, int64_t weight_off,
+                                                             int64_t chunk_off) {
+    // weight_off / chunk_off: a row-block plan numbers weights and chunks as the WHOLE matrix's plan does
+    // (weight of local row r = Ap[r] + k r + weight_off, local chunk c = whole chunk c + chunk_off), so that its
+    // boundaries are the whole plan's; both 0 otherwise.  A block starts on a multiple of 4 rows of the whole.
     const int64_t c = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (c > n_chunks) return;
     if (c == n_chunks) {
         chunk_row[c] = n_rows;
         return;
     }
-    const int64_t target = c * q;            // first r in [0, n_rows] with Ap[r] + k r >= target
+    const int64_t target = (c + chunk_off) * q - weight_off;   // first r in [0, n_rows] with Ap[r] + k r >= target
     int64_t lo = 0, hi = n_rows;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
@@ -191,8 +246,7 @@ int allow_dynamic_lds(const void* kernel, size_t bytes) {
 }
 
 int long_steps_for(const Plan& p) {
-    static const int forced = [] { const char* e = getenv("MI355_SPMV_LONG_STEPS"); return e ? atoi(e) : 0; }();
-    if (forced > 0) return forced;
+    if (p.knob.long_steps > 0) return p.knob.long_steps;
     // measured on the power-law stand-ins (us, 1 / 2 / 4 / 8 / 16 steps): web-Google 139 / 120 / 99 / 104 / 105,
     // R-MAT-24 light 2 820 at 4 vs 3 200 at 16; uniform plans keep the long chain (their rows rarely need it)
     return p.balanced ? 4 : kLongSteps;
@@ -204,9 +258,9 @@ int decide_balance(Plan& p) {
     p.rows_cap = int(p.rows_per_chunk);
     p.n_chunks = p.rows_per_chunk > 0 ? (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk : 0;
     if (p.n_chunks < 1) p.n_chunks = 1;
-    const char* ev = getenv("MI355_SPMV_BALANCE");          // 0 = never, 1 = always, unset = measure
-    if (p.n_rows <= 0 || p.nnz <= 0 || (ev && atoi(ev) == 0)) return MI355_SPMV_OK;
-    bool want = ev && atoi(ev) != 0;
+    const int ev = p.knob.balance;                          // 0 = never, 1 = always, -1 = measure
+    if (p.n_rows <= 0 || p.nnz <= 0 || ev == 0) return MI355_SPMV_OK;
+    bool want = ev > 0;
     if (!want && p.n_chunks >= 2) {
         std::lock_guard<std::mutex> lock(g_analysis_mutex);
         long long* buf = analysis_buffer();
@@ -238,10 +292,10 @@ int decide_balance(Plan& p) {
     int64_t r0 = p.rows_per_chunk;
     if (r0 > kMaxChunkRows / 2) r0 = kMaxChunkRows / 2;
     if (r0 < 4) r0 = 4;
-    p.bal_k = (p.nnz + p.n_rows - 1) / p.n_rows;
+    p.bal_k = (p.nnz - p.nnz_begin + p.n_rows - 1) / p.n_rows;
     if (p.bal_k < 1) p.bal_k = 1;
     p.bal_q = 2 * p.bal_k * r0;
-    const int64_t weight = p.nnz + p.bal_k * int64_t(p.n_rows);
+    const int64_t weight = (p.nnz - p.nnz_begin) + p.bal_k * int64_t(p.n_rows);
     p.n_chunks = (weight + p.bal_q - 1) / p.bal_q;
     if (p.n_chunks < 1) p.n_chunks = 1;
     p.rows_cap = int(2 * r0 + 4);              // Q / k rows, + 3 for the round-down of the boundaries
@@ -268,10 +322,10 @@ __global__ __launch_bounds__(kBlock) void giant_scan_kernel(int32_t n_rows, cons
 int find_giant_rows(Plan& p) {
     p.n_giant = 0;
     p.n_giant_slices = 0;
-    const char* ev = getenv("MI355_SPMV_GIANT");                 // 0 disables (tuning / tests)
-    if (!p.balanced || (ev && atoi(ev) == 0)) return MI355_SPMV_OK;
-    static const int64_t forced_len = [] { const char* e = getenv("MI355_SPMV_GIANT_ROW"); return e ? atoll(e) : 0ll; }();
-    p.giant_len = forced_len >= 4096 ? forced_len : kGiantRow;
+    // (a row-block plan does what the whole matrix's plan decided: p.giant_enabled / p.giant_len are inherited)
+    if (!p.balanced || (p.is_block ? !p.giant_enabled : p.knob.giant == 0)) { p.giant_enabled = false; return MI355_SPMV_OK; }
+    if (!p.is_block) p.giant_len = p.knob.giant_row >= 4096 ? p.knob.giant_row : kGiantRow;
+    p.giant_enabled = false;
     static_assert(1 + 2 * size_t(kMaxGiantRows) <= kAnalysisWords, "analysis buffer");
     std::lock_guard<std::mutex> lock(g_analysis_mutex);
     long long* buf = analysis_buffer();
@@ -294,7 +348,9 @@ int find_giant_rows(Plan& p) {
         return MI355_SPMV_EHIP;
     }
     const long long count = h[0];
-    if (count <= 0 || count > kMaxGiantRows) return MI355_SPMV_OK;   // none, or too many to be "a few dense rows"
+    if (count > kMaxGiantRows) return MI355_SPMV_OK;   // too many to be "a few dense rows": they stay with their workgroups
+    p.giant_enabled = true;                            // (a block of this matrix may hold some even if this one holds none)
+    if (count <= 0) return MI355_SPMV_OK;
     std::pair<long long, long long> rows[kMaxGiantRows];
     for (long long i = 0; i < count; ++i) rows[i] = {h[1 + 2 * i], h[2 + 2 * i]};
     std::sort(rows, rows + count);                                // the device appended them in any order
@@ -318,12 +374,88 @@ int build_chunk_table(Plan& p) {
     const unsigned g = unsigned((p.n_chunks + 1 + kBlock - 1) / kBlock);
     if (p.off_type == MI355_OFF_I32)
         hipLaunchKernelGGL((chunk_table_kernel<int32_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
-                           static_cast<const int32_t*>(p.Ap), p.bal_k, p.bal_q, p.n_chunks, p.chunk_row);
+                           static_cast<const int32_t*>(p.Ap), p.bal_k, p.bal_q, p.n_chunks, p.chunk_row,
+                           p.is_block ? p.block_weight_off : -p.nnz_begin, p.is_block ? p.block_chunk_begin : int64_t(0));
     else
         hipLaunchKernelGGL((chunk_table_kernel<int64_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
-                           static_cast<const int64_t*>(p.Ap), p.bal_k, p.bal_q, p.n_chunks, p.chunk_row);
+                           static_cast<const int64_t*>(p.Ap), p.bal_k, p.bal_q, p.n_chunks, p.chunk_row,
+                           p.is_block ? p.block_weight_off : -p.nnz_begin, p.is_block ? p.block_chunk_begin : int64_t(0));
     MI355_HIP_TRY(hipGetLastError());
     MI355_HIP_TRY(hipStreamSynchronize(nullptr));   // the first execute may come on any stream
+    return MI355_SPMV_OK;
+}
+
+// ---- partition into row blocks (multi-GPU; include/mi355_spmv.h "row-block plans") -----------------
+// Boundary b of `parts` blocks: the first UNIT whose first row starts at or after nonzero b * nnz / parts.
+// A unit is a chunk of the plan (VECTOR / LIGHT: a block then owns whole chunks, so it can reproduce the whole
+// plan's per-chunk decisions) or 4 rows (MERGE: any multiple of 4 rows keeps the 16-byte phase rule simple).
+template <typename off_t>
+__global__ __launch_bounds__(kBlock) void partition_kernel(int32_t n_rows, const off_t* __restrict__ Ap,
+                                                           const int32_t* __restrict__ table, int64_t rows_per_unit,
+                                                           int64_t n_units, int parts, long long* out) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b > parts) return;
+    auto unit_row = [&](int64_t u) -> int64_t {
+        if (u >= n_units) return n_rows;
+        return table ? int64_t(table[u]) : min(u * rows_per_unit, int64_t(n_rows));
+    };
+    const int64_t first = int64_t(Ap[0]), last = int64_t(Ap[n_rows]);
+    int64_t u = 0;
+    if (b == parts) u = n_units;
+    else if (b > 0) {
+        const int64_t target = first + int64_t((__int128)(last - first) * b / parts);
+        int64_t lo = 0, hi = n_units;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (int64_t(Ap[unit_row(mid)]) >= target) hi = mid;
+            else lo = mid + 1;
+        }
+        u = lo;
+    }
+    const int64_t r = unit_row(u);
+    out[3 * b + 0] = r;
+    out[3 * b + 1] = u;
+    out[3 * b + 2] = int64_t(Ap[r]);
+}
+
+int partition_plan(const Plan& p, int parts, int64_t* row_cuts, int64_t* chunk_cuts, int64_t* nnz_cuts) {
+    if (p.n_rows <= 0) {
+        for (int b = 0; b <= parts; ++b) { row_cuts[b] = 0; chunk_cuts[b] = 0; nnz_cuts[b] = p.nnz_begin; }
+        return MI355_SPMV_OK;
+    }
+    if (size_t(parts + 1) * 3 > kAnalysisWords) { set_error("plan_partition: too many parts"); return MI355_SPMV_EINVAL; }
+    const bool chunked = p.kind != MI355_KIND_MERGE;
+    const int32_t* table = (chunked && p.balanced) ? p.chunk_row : nullptr;
+    const int64_t rows_per_unit = chunked ? (p.rows_per_chunk > 0 ? p.rows_per_chunk : 4) : 4;
+    const int64_t n_units = table ? p.n_chunks : (int64_t(p.n_rows) + rows_per_unit - 1) / rows_per_unit;
+    std::lock_guard<std::mutex> lock(g_analysis_mutex);
+    long long* buf = analysis_buffer();
+    if (!buf) { set_error("plan_partition: no device scratch"); return MI355_SPMV_ENOMEM; }
+    const unsigned g = unsigned((parts + 1 + kBlock - 1) / kBlock);
+    if (p.off_type == MI355_OFF_I32)
+        hipLaunchKernelGGL((partition_kernel<int32_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
+                           static_cast<const int32_t*>(p.Ap), table, rows_per_unit, n_units, parts, buf);
+    else
+        hipLaunchKernelGGL((partition_kernel<int64_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
+                           static_cast<const int64_t*>(p.Ap), table, rows_per_unit, n_units, parts, buf);
+    hipError_t e = hipGetLastError();
+    long long* h = new (std::nothrow) long long[size_t(parts + 1) * 3];
+    if (!h) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemcpy(h, buf, size_t(parts + 1) * 3 * sizeof(long long), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        delete[] h;
+        set_error("plan_partition: %s", hipGetErrorString(e));
+        return MI355_SPMV_EHIP;
+    }
+    for (int b = 0; b <= parts; ++b) {
+        row_cuts[b] = h[3 * b];
+        chunk_cuts[b] = chunked ? h[3 * b + 1] : 0;
+        nnz_cuts[b] = h[3 * b + 2];
+        if (b > 0 && row_cuts[b] < row_cuts[b - 1]) {   // (monotone by construction; keep it so whatever Ap holds)
+            row_cuts[b] = row_cuts[b - 1]; chunk_cuts[b] = chunk_cuts[b - 1]; nnz_cuts[b] = nnz_cuts[b - 1];
+        }
+    }
+    delete[] h;
     return MI355_SPMV_OK;
 }
 
@@ -376,13 +508,11 @@ int pick_window_elems(Plan& p, int64_t rows_per_workgroup) {
     const int val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
     const int cap = (p.window_bytes > 0 ? p.window_bytes : kWindowBytes) / val_bytes;
     p.window_from_band = false;
-    const char* force = getenv("MI355_SPMV_WINDOW");
-    if (force) return atoi(force) ? cap : 0;
+    if (p.knob.window >= 0) return p.knob.window ? cap : 0;
     if (!p.probe_ok) return 0;
     const int64_t span = (p.band_hi - p.band_lo + 1) + rows_per_workgroup;
     // the band (plus the chunk's rows) all but fits: no need to sample every chunk
-    const char* band = getenv("MI355_SPMV_WINDOW_FROM_BAND");
-    p.window_from_band = band ? atoi(band) != 0 : span <= int64_t(cap) * 9 / 8;
+    p.window_from_band = p.knob.window_from_band >= 0 ? p.knob.window_from_band != 0 : span <= int64_t(cap) * 9 / 8;
     p.n_seg = 0;
     if (span <= int64_t(cap) * 3 / 2) {
         // LDS is occupancy: take what the span needs (a sampled window is widened by an eighth + 64 per side)
@@ -391,8 +521,7 @@ int pick_window_elems(Plan& p, int64_t rows_per_workgroup) {
         return int(std::min<int64_t>(elems, cap));
     }
     // one window cannot hold the band: do a few narrow ones?  (MI355_SPMV_SEGMENTS=0 disables)
-    const char* seg = getenv("MI355_SPMV_SEGMENTS");
-    if (!(seg && atoi(seg) == 0)) {
+    if (p.knob.segments != 0) {
         const int64_t need = cluster_bands(p, rows_per_workgroup);
         // up to 1.25x: the tail of the last band is cut and falls back to global loads; the
         // row-based kinds then shrink their chunk so that everything fits (segment_rows_fit)
@@ -423,8 +552,8 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
         const int64_t pass = int64_t(block_threads / p.lanes_per_row) * R;
         int64_t rows = pick_rows_per_chunk(p.nnz, p.n_rows, p.lanes_per_row, R, block_threads, nnz_per_chunk);
         if (div > 1) rows = (rows / div + pass - 1) / pass * pass;
-        if (const char* e = getenv("MI355_SPMV_ROWS_PER_CHUNK")) {
-            int64_t r = atoll(e);
+        if (p.knob.rows_per_chunk > 0) {
+            int64_t r = p.knob.rows_per_chunk;
             r = (r + pass - 1) / pass * pass;
             if (r >= pass && r <= kMaxChunkRows) rows = r;
         }
@@ -443,7 +572,7 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
         // Whole rounds: with a few chunks per workgroup slot, a last round that is a third full costs a quarter
         // of the kernel (2^20 rows: 1 024 chunks on 768 slots).  Shrink the chunk so that the count is a multiple
         // of the slots the plan's LDS and registers leave on the chip.
-        if (!getenv("MI355_SPMV_ROWS_PER_CHUNK") && p.n_seg < 2) {
+        if (p.knob.rows_per_chunk <= 0 && p.n_seg < 2) {
             const size_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
             const size_t lds = chunk_lds_bytes(p.window_elems, int(p.rows_per_chunk), off_bytes, val_bytes) + 1024;
             int64_t per_cu = int64_t(160 * 1024 / lds);
@@ -463,8 +592,8 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
             }
         }
     };
-    const char* force = getenv("MI355_SPMV_BLOCK");
-    if (force ? atoi(force) == kWideBlock : allow_wide) {
+    const bool force = p.knob.block > 0;
+    if (force ? p.knob.block == kWideBlock : allow_wide) {
         shape(kWideBlock, 65536);   // (3 072- and 3 584-row chunks with 79 KB of LDS measured worse: 189-194 vs 180 us)
         const int64_t mean = p.n_rows > 0 ? (p.nnz + p.n_rows - 1) / p.n_rows : 1;
         // keep it when (a) the ">= 4 chunks per CU" rule left the chunk long and (b) one window placed from the
@@ -480,7 +609,7 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
     // gathers, 704 us): gfx950 lets a workgroup take more than the default 64 KB of LDS, and two workgroups of
     // 512 threads with ~78 KB each still fit a CU.  The chunk is then as long as the band leaves room for.
     if (allow_wide && !force && p.probe_ok && !(p.window_elems > 0 && p.n_seg < 2 && p.window_from_band) &&
-        !getenv("MI355_SPMV_WINDOW") && !getenv("MI355_SPMV_ROWS_PER_CHUNK")) {
+        p.knob.window < 0 && p.knob.rows_per_chunk <= 0) {
         const int64_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
         const int64_t band = p.band_hi - p.band_lo + 1;
         const int64_t pass = int64_t(kWideBlock / p.lanes_per_row) * R;

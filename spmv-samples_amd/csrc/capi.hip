@@ -182,8 +182,18 @@ int mi355_spmv_device_count(void) {
     return found;
 }
 
-int mi355_spmv_plan_create(mi355_spmv_plan** out, int kind, int off_type, int val_type, int32_t n_rows,
-                           int32_t n_cols, int64_t nnz, const void* Ap, const int32_t* Aj, int flags) {
+// Common body of plan_create / plan_create_block.  blk == nullptr: an ordinary plan (Ap[0] == 0).
+// blk != nullptr: rows of a larger CSR (Ap[0] = blk->phase in 0..3, nnz = END offset); VECTOR / LIGHT blocks
+// inherit the launch shape of the whole matrix's plan so that every row is summed exactly as there.
+struct BlockSpec {
+    const mi355_spmv_plan_shape* whole;   // may be null (MERGE, or an independent block)
+    int64_t row_begin, chunk_begin, n_chunks, nnz_begin_whole;
+    int phase;
+};
+
+static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int val_type, int32_t n_rows,
+                            int32_t n_cols, int64_t nnz, const void* Ap, const int32_t* Aj, int flags,
+                            const BlockSpec* blk) {
     g_err[0] = 0;
     if (!out) { set_error("plan_create: null plan pointer"); return MI355_SPMV_EINVAL; }
     *out = nullptr;
@@ -191,37 +201,89 @@ int mi355_spmv_plan_create(mi355_spmv_plan** out, int kind, int off_type, int va
     if (off_type != MI355_OFF_I32 && off_type != MI355_OFF_I64) { set_error("plan_create: unknown offset type %d", off_type); return MI355_SPMV_EINVAL; }
     if (val_type != MI355_VAL_F32 && val_type != MI355_VAL_F64) { set_error("plan_create: unknown value type %d", val_type); return MI355_SPMV_EINVAL; }
     if (n_rows < 0 || n_cols < 0 || nnz < 0) { set_error("plan_create: negative size"); return MI355_SPMV_EINVAL; }
-    if (off_type == MI355_OFF_I32 && nnz > INT32_MAX) { set_error("plan_create: nnz does not fit 32-bit offsets"); return MI355_SPMV_EINVAL; }
+    // the kernels step 16-byte groups past a row's end before masking: 32-bit index arithmetic needs headroom
+    if (off_type == MI355_OFF_I32 && nnz > INT32_MAX - 4096) { set_error("plan_create: nnz does not fit 32-bit offsets with headroom (use 64-bit offsets)"); return MI355_SPMV_EINVAL; }
     if (n_rows > 0 && !Ap) { set_error("plan_create: null Ap"); return MI355_SPMV_EINVAL; }
     if (nnz > 0 && !Aj) { set_error("plan_create: null Aj"); return MI355_SPMV_EINVAL; }
     if (nnz > 0 && n_cols == 0) { set_error("plan_create: nonzeros but no columns"); return MI355_SPMV_EINVAL; }
+    if (blk && (blk->phase < 0 || blk->phase > 3 || blk->phase > nnz)) { set_error("plan_create_block: Ap[0] must be 0..3"); return MI355_SPMV_EINVAL; }
 
     mi355_spmv_plan* h = new (std::nothrow) mi355_spmv_plan();
     if (!h) { set_error("plan_create: host allocation failed"); return MI355_SPMV_ENOMEM; }
     Plan& p = h->p;
-    memset(&p, 0, sizeof(p));
+    memset(static_cast<void*>(&p), 0, sizeof(p));
+    p.knob = knobs();
     p.kind = kind; p.off_type = off_type; p.val_type = val_type; p.flags = flags;
     p.n_rows = n_rows; p.n_cols = n_cols; p.nnz = nnz; p.Ap = Ap; p.Aj = Aj;
+    p.nnz_begin = blk ? blk->phase : 0;
     p.elems_per_lane = 4;
     p.alpha = 1.0;
     p.beta = 0.0;
-    {
-        const int st = probe_structure(p);   // one tiny kernel + one 16-byte copy (synchronises)
-        if (st != MI355_SPMV_OK) { delete h; return st; }
-    }
-    switch (kind) {
-        case MI355_KIND_VECTOR: shape_vector(p); break;
-        case MI355_KIND_MERGE:  shape_merge(p); break;
-        case MI355_KIND_LIGHT:  shape_light(p); break;
-    }
-    if (kind == MI355_KIND_VECTOR || kind == MI355_KIND_LIGHT) {
-        const int st = decide_balance(p);    // heaviest uniform chunk vs the mean (synchronises)
-        if (st != MI355_SPMV_OK) { delete h; return st; }
-        if (kind == MI355_KIND_VECTOR) reshape_vector_balanced(p);
-        else reshape_light_balanced(p);
-        const int st2 = find_giant_rows(p);  // balanced plans: rows too long for one workgroup (synchronises)
+    const mi355_spmv_plan_shape* w = (blk && kind != MI355_KIND_MERGE) ? blk->whole : nullptr;
+    if (w) {
+        if (w->struct_bytes != int32_t(sizeof(mi355_spmv_plan_shape)) || w->kind != kind || w->off_type != off_type ||
+            w->val_type != val_type) {
+            set_error("plan_create_block: the shape is of another kind / type / library version");
+            delete h;
+            return MI355_SPMV_EINVAL;
+        }
+        if (n_rows > 0 && ((blk->row_begin & 3) != 0 ||
+                           (w->balanced_chunks == 0 && w->rows_per_chunk > 0 && blk->row_begin % w->rows_per_chunk != 0))) {
+            set_error("plan_create_block: row_begin is not a chunk boundary of the whole plan");
+            delete h;
+            return MI355_SPMV_EINVAL;
+        }
+        p.is_block = true;
+        p.block_row_begin = blk->row_begin;
+        p.block_chunk_begin = blk->chunk_begin;
+        p.lanes_per_row = w->lanes_per_row;
+        p.elems_per_lane = w->elems_per_lane;
+        p.block_threads = w->block_threads;
+        p.rows_per_chunk = w->rows_per_chunk;
+        p.rows_cap = w->rows_cap;
+        p.balanced = w->balanced_chunks != 0;
+        p.bal_k = w->bal_k;
+        p.bal_q = w->bal_q;
+        p.block_weight_off = (blk->nnz_begin_whole - blk->phase) + w->bal_k * blk->row_begin;
+        p.giant_enabled = w->giant_rows_enabled != 0;
+        p.giant_len = w->giant_len;
+        p.knob.long_steps = w->long_steps;          // (0 = the default rule, which depends on `balanced` only)
+        p.window_elems = w->window_elems;
+        p.window_bytes = w->window_bytes;
+        p.window_from_band = w->window_from_band != 0;
+        p.n_seg = w->window_segments >= 2 ? w->window_segments : 0;
+        p.probe_ok = w->probe_ok != 0;
+        // (column - row) bands were measured with whole-matrix row numbers; this plan's rows start at 0
+        p.band_lo = w->band_lo + blk->row_begin;
+        p.band_hi = w->band_hi + blk->row_begin;
+        for (int i = 0; i < 4; ++i) { p.seg_lo[i] = w->seg_lo[i] + blk->row_begin; p.seg_hi[i] = w->seg_hi[i] + blk->row_begin; }
+        p.n_chunks = p.balanced ? blk->n_chunks
+                                : (p.rows_per_chunk > 0 ? (int64_t(n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk : 0);
+        if (p.n_chunks < 1) p.n_chunks = 1;
+        p.n_kernels = 1;
+        if (kind == MI355_KIND_VECTOR) block_grid_vector(p); else block_grid_light(p);
+        const int st2 = find_giant_rows(p);
         if (st2 != MI355_SPMV_OK) { delete h; return st2; }
         if (p.n_giant > 0) p.n_kernels = 3;
+    } else {
+        {
+            const int st = probe_structure(p);   // one tiny kernel + one 16-byte copy (synchronises)
+            if (st != MI355_SPMV_OK) { delete h; return st; }
+        }
+        switch (kind) {
+            case MI355_KIND_VECTOR: shape_vector(p); break;
+            case MI355_KIND_MERGE:  shape_merge(p); break;
+            case MI355_KIND_LIGHT:  shape_light(p); break;
+        }
+        if (kind == MI355_KIND_VECTOR || kind == MI355_KIND_LIGHT) {
+            const int st = decide_balance(p);    // heaviest uniform chunk vs the mean (synchronises)
+            if (st != MI355_SPMV_OK) { delete h; return st; }
+            if (kind == MI355_KIND_VECTOR) reshape_vector_balanced(p);
+            else reshape_light_balanced(p);
+            const int st2 = find_giant_rows(p);  // balanced plans: rows too long for one workgroup (synchronises)
+            if (st2 != MI355_SPMV_OK) { delete h; return st2; }
+            if (p.n_giant > 0) p.n_kernels = 3;
+        }
     }
     int st = plan_alloc_scratch(p);
     if (st == MI355_SPMV_OK) st = build_chunk_table(p);
@@ -231,6 +293,57 @@ int mi355_spmv_plan_create(mi355_spmv_plan** out, int kind, int off_type, int va
         return st;
     }
     *out = h;
+    return MI355_SPMV_OK;
+}
+
+int mi355_spmv_plan_create(mi355_spmv_plan** out, int kind, int off_type, int val_type, int32_t n_rows,
+                           int32_t n_cols, int64_t nnz, const void* Ap, const int32_t* Aj, int flags) {
+    return plan_create_impl(out, kind, off_type, val_type, n_rows, n_cols, nnz, Ap, Aj, flags, nullptr);
+}
+
+int mi355_spmv_plan_create_block(mi355_spmv_plan** out, int kind, int off_type, int val_type,
+                                 const mi355_spmv_plan_shape* whole, int64_t row_begin, int64_t chunk_begin,
+                                 int64_t n_chunks, int64_t nnz_begin_whole, int32_t n_rows, int32_t n_cols,
+                                 int64_t nnz_end, const void* Ap, const int32_t* Aj, int flags) {
+    BlockSpec blk{whole, row_begin, chunk_begin, n_chunks, nnz_begin_whole, int(nnz_begin_whole & 3)};
+    if (n_rows == 0) { blk.phase = 0; nnz_end = 0; }   // an empty block owns no element of its view
+    return plan_create_impl(out, kind, off_type, val_type, n_rows, n_cols, nnz_end, Ap, Aj, flags, &blk);
+}
+
+int mi355_spmv_plan_get_shape(const mi355_spmv_plan* h, mi355_spmv_plan_shape* sh) {
+    if (!h || !sh) { set_error("plan_get_shape: null argument"); return MI355_SPMV_EINVAL; }
+    const Plan& p = h->p;
+    memset(sh, 0, sizeof(*sh));
+    sh->struct_bytes = int32_t(sizeof(*sh));
+    sh->kind = p.kind; sh->off_type = p.off_type; sh->val_type = p.val_type;
+    sh->n_rows = p.n_rows; sh->n_cols = p.n_cols; sh->nnz = p.nnz;
+    sh->lanes_per_row = p.lanes_per_row; sh->elems_per_lane = p.elems_per_lane;
+    sh->block_threads = p.block_threads > 0 ? p.block_threads : kBlock;
+    sh->balanced_chunks = p.balanced ? 1 : 0;
+    sh->rows_cap = p.rows_cap;
+    sh->giant_rows_enabled = p.giant_enabled ? 1 : 0;
+    sh->rows_per_chunk = p.rows_per_chunk; sh->n_chunks = p.n_chunks;
+    sh->bal_k = p.bal_k; sh->bal_q = p.bal_q; sh->giant_len = p.giant_len;
+    sh->window_elems = p.window_elems; sh->window_bytes = p.window_bytes;
+    sh->window_from_band = p.window_from_band ? 1 : 0;
+    sh->window_segments = p.n_seg >= 2 ? p.n_seg : (p.window_elems > 0 ? 1 : 0);
+    sh->probe_ok = p.probe_ok ? 1 : 0;
+    sh->long_steps = p.knob.long_steps;
+    // bands in whole-matrix row numbering (a block plan stores them shifted by its first row)
+    sh->band_lo = p.band_lo - p.block_row_begin; sh->band_hi = p.band_hi - p.block_row_begin;
+    for (int i = 0; i < 4; ++i) { sh->seg_lo[i] = p.seg_lo[i] - p.block_row_begin; sh->seg_hi[i] = p.seg_hi[i] - p.block_row_begin; }
+    return MI355_SPMV_OK;
+}
+
+int mi355_spmv_plan_partition(const mi355_spmv_plan* h, int parts, int64_t* row_cuts, int64_t* chunk_cuts,
+                              int64_t* nnz_cuts) {
+    g_err[0] = 0;
+    if (!h || parts < 1 || !row_cuts || !chunk_cuts || !nnz_cuts) { set_error("plan_partition: bad argument"); return MI355_SPMV_EINVAL; }
+    return partition_plan(h->p, parts, row_cuts, chunk_cuts, nnz_cuts);
+}
+
+int mi355_spmv_knobs_reload(void) {
+    knobs_reload();
     return MI355_SPMV_OK;
 }
 
@@ -314,6 +427,7 @@ int mi355_spmv_plan_get_info(const mi355_spmv_plan* h, mi355_spmv_plan_info* inf
     info->balanced_chunks = p.balanced ? 1 : 0;
     info->rows_cap = p.rows_cap;
     info->n_chunks = p.n_chunks;
+    snprintf(info->knobs, sizeof(info->knobs), "%s", p.knob.text);
     return MI355_SPMV_OK;
 }
 

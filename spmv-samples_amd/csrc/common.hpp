@@ -44,10 +44,46 @@ __device__ __forceinline__ unsigned xcd_contiguous_id(unsigned bid, unsigned nbl
     return base + k;
 }
 
+// Tuning / test knobs: every MI355_* environment variable the plan path honours, parsed ONCE per process
+// (mi355_spmv_knobs_reload re-reads them), copied into each plan at creation and echoed by
+// mi355_spmv_plan_get_info (`knobs`: the non-default ones), so a stray variable is visible in every report.
+// -1 / 0 = not set.  None of them can change a result beyond the summation order.
+struct Knobs {
+    int lanes = 0;             // MI355_SPMV_LANES            T of VECTOR / LIGHT (2..64)
+    int block = 0;             // MI355_SPMV_BLOCK            256 | 512 threads (VECTOR / LIGHT)
+    int64_t rows_per_chunk = 0;// MI355_SPMV_ROWS_PER_CHUNK
+    int window = -1;           // MI355_SPMV_WINDOW           0 = never stage x in LDS, 1 = always
+    int window_from_band = -1; // MI355_SPMV_WINDOW_FROM_BAND 0 = sample every chunk, 1 = place from the probe's band
+    int segments = -1;         // MI355_SPMV_SEGMENTS         0 = no multi-band windows
+    int balance = -1;          // MI355_SPMV_BALANCE          0 = equal-row chunks, 1 = weight-cut chunks
+    int long_steps = 0;        // MI355_SPMV_LONG_STEPS       steps after which a row goes to the long-row pass
+    int giant = -1;            // MI355_SPMV_GIANT            0 = no giant-row slices
+    int64_t giant_row = 0;     // MI355_SPMV_GIANT_ROW        nonzeros beyond which a row is giant (>= 4096)
+    int plain = 0;             // MI355_SPMV_PLAIN            1 = the 4-byte-per-lane fallback kernels
+    int light_blocks_per_cu = 0;   // MI355_LIGHT_BLOCKS_PER_CU
+    int light_chunk_div = 0;   // MI355_LIGHT_CHUNK_DIV
+    int merge_block = 0;       // MI355_MERGE_BLOCK           256 | 512
+    int merge_tps = 0;         // MI355_MERGE_TPS             tiles per run
+    int merge_search_lanes = 0;// MI355_MERGE_SEARCH_LANES    1 | 4 | 16
+    int merge_fused = -1;      // MI355_MERGE_FUSED           0 = never the single-launch small-grid kernel, 1 = whenever legal
+    char text[160] = "";       // the non-default ones, "NAME=value ..." (as read)
+};
+const Knobs& knobs();          // parsed on first use
+void knobs_reload();
+
 struct Plan {
     int kind, off_type, val_type, flags;
     int32_t n_rows, n_cols;
-    int64_t nnz;
+    int64_t nnz;               // END offset of the nonzeros: Ap[n_rows] (= their count unless nnz_begin > 0)
+    int64_t nnz_begin;         // Ap[0]: 0, or 1..3 in a row-block plan whose arrays are a 16-byte-aligned view
+                               // of a larger CSR (plan_create_block): elements below it belong to no row
+    Knobs knob;                // the knobs this plan was shaped under
+    // row-block plans (mi355_spmv_plan_create_block): launch shape inherited from the whole matrix's plan
+    bool is_block;
+    int64_t block_row_begin;   // first row of the block in the whole matrix
+    int64_t block_chunk_begin; // first chunk of the block in the whole plan's chunk numbering
+    int64_t block_weight_off;  // weight-cut plans: (global nnz offset of the block - nnz_begin) + bal_k * block_row_begin
+    bool giant_enabled;        // weight-cut plans: whether rows beyond giant_len are cut into slices
     const void* Ap;
     const int32_t* Aj;
     // launch shape
@@ -127,5 +163,9 @@ void shape_merge(Plan& p);
 void shape_light(Plan& p);
 void reshape_vector_balanced(Plan& p);
 void reshape_light_balanced(Plan& p);
+void block_grid_vector(Plan& p);   // row-block plans: grid / names from the inherited shape and the block's n_chunks
+void block_grid_light(Plan& p);
+// nnz-balanced cuts on the plan's chunk boundaries (analyze.hip; reads Ap on the device, synchronises)
+int partition_plan(const Plan& p, int parts, int64_t* row_cuts, int64_t* chunk_cuts, int64_t* nnz_cuts);
 
 }  // namespace mi355

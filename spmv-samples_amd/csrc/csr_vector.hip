@@ -81,10 +81,10 @@ template <typename val_t> constexpr int rows_in_flight() { return sizeof(val_t) 
 
 #ifndef MI355_TU_F64   // the host-side shape functions live in the fp32 translation unit only
 void shape_vector(Plan& p) {
-    p.lanes_per_row = pick_lanes_per_row(p.nnz, p.n_rows, p.elems_per_lane);
+    p.lanes_per_row = pick_lanes_per_row(p.nnz - p.nnz_begin, p.n_rows, p.elems_per_lane);
     const int R = p.val_type == MI355_VAL_F64 ? rows_in_flight<double>() : rows_in_flight<float>();
-    if (const char* e = getenv("MI355_SPMV_LANES")) {          // tuning knob
-        const int t = atoi(e);
+    {                                                          // tuning knob
+        const int t = p.knob.lanes;
         if (t == 2 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64) p.lanes_per_row = t;
     }
     // (512-thread workgroups need <= 128 VGPRs: not the fp32 kernels with 64-bit offsets, 180)
@@ -105,6 +105,12 @@ void reshape_vector_balanced(Plan& p) {
     p.n_tiles = p.n_chunks;
     p.window_elems = pick_window_elems(p, p.rows_cap);
     if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }   // (the multi-band plan is sized for uniform chunks)
+}
+
+void block_grid_vector(Plan& p) {
+    p.grid_blocks = p.n_chunks;
+    p.n_tiles = p.n_chunks;
+    snprintf(p.main_kernel, sizeof(p.main_kernel), "csr_vector_window_kernel");
 }
 
 #endif  // MI355_TU_F64
@@ -136,10 +142,14 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
             hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, R, 0, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
         break;
     if constexpr (BLOCK == kBlock) if (p.balanced) {   // vector width per chunk (chunk_rows_any); the T of the template is not used
-        if (p.window_elems > 0)
+        // (the weight-cut layout holds up to 2 K rows of 64-bit bounds and fp64 results next to the window: past 64 KB)
+        if (p.window_elems > 0) {
+            if (const int st = allow_dynamic_lds((const void*)csr_vector_window_kernel<BLOCK, 2, R, 1, true, off_t, val_t>, lds)) return st;
             hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, 2, R, 1, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);
-        else
+        } else {
+            if (const int st = allow_dynamic_lds((const void*)csr_vector_window_kernel<BLOCK, 2, R, 0, true, off_t, val_t>, lds)) return st;
             hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, 2, R, 0, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);
+        }
         MI355_HIP_TRY(hipGetLastError());
         return launch_giant_rows<off_t, val_t>(p, Ap, Ax, x, y, s);   // (rows too long for one workgroup, if any)
     }
@@ -194,7 +204,7 @@ int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* 
     // that passes an offset view gets the 4-byte-per-lane form instead.
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
-    static const bool force_plain = [] { const char* e = getenv("MI355_SPMV_PLAIN"); return e && atoi(e) != 0; }();   // tuning / tests
+    const bool force_plain = p.knob.plain != 0 && !p.is_block;   // tuning / tests (a block keeps the whole plan's order)
     if (aligned && p.nnz >= 4 && !force_plain)
         return p.block_threads == kWideBlock ? launch_vector_window<kWideBlock, off_t, val_t>(p, Ap, Ax, x, y, s)
                                              : launch_vector_window<kBlock, off_t, val_t>(p, Ap, Ax, x, y, s);

@@ -216,8 +216,7 @@ static int64_t light_resident(const Plan& p, int64_t rows) {
     // persistent grid = what stays resident on a CU: bounded by LDS (160 KB: the chunk's layout + ~1 KB static)
     // and by registers (3 workgroups of 256 threads, 2 of 512).  Asking for more than fits leaves the surplus
     // workgroups to start when the others have finished everything (4 asked / 3 resident: 207 vs 200 us).
-    const char* er = getenv("MI355_LIGHT_BLOCKS_PER_CU");
-    if (er && atoi(er) > 0) return int64_t(kCus) * atoi(er);
+    if (p.knob.light_blocks_per_cu > 0) return int64_t(kCus) * p.knob.light_blocks_per_cu;
     const size_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
     const size_t lds = chunk_lds_bytes(p.window_elems, int(rows), off_bytes, val_bytes) + 1024;
     int64_t per_cu = int64_t(160 * 1024 / lds);
@@ -238,13 +237,13 @@ static int64_t light_grid(const Plan& p, int64_t n_chunks, int64_t resident) {
 }
 
 void shape_light(Plan& p) {
-    p.lanes_per_row = pick_lanes_per_row(p.nnz, p.n_rows, p.elems_per_lane);
+    p.lanes_per_row = pick_lanes_per_row(p.nnz - p.nnz_begin, p.n_rows, p.elems_per_lane);
     const int R = p.val_type == MI355_VAL_F64 ? light_rows_in_flight<double>() : light_rows_in_flight<float>();
-    const char* ev = getenv("MI355_LIGHT_CHUNK_DIV");
+    const int div = p.knob.light_chunk_div;
     // chunks: the static kind's size (halving them cost 6 % on the S32-band target: the
     // window of x is staged per chunk), never below one pass of the workgroup
     // (512-thread workgroups only with 32-bit offsets: under the 128-VGPR cap the 64-bit kernels spill 80 registers)
-    shape_chunks(p, R, ev && atoi(ev) > 0 ? atoi(ev) : 1, p.off_type == MI355_OFF_I32);
+    shape_chunks(p, R, div > 0 ? div : 1, p.off_type == MI355_OFF_I32);
     p.n_tiles = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
     p.grid_blocks = light_grid(p, p.n_tiles, light_resident(p, p.rows_per_chunk));
     p.n_kernels = 1;
@@ -260,6 +259,12 @@ void reshape_light_balanced(Plan& p) {
     p.window_elems = pick_window_elems(p, p.rows_cap);
     if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }
     p.grid_blocks = light_grid(p, p.n_chunks, light_resident(p, p.rows_cap));
+}
+
+void block_grid_light(Plan& p) {
+    p.n_tiles = p.n_chunks;
+    p.grid_blocks = light_grid(p, p.n_chunks, light_resident(p, p.balanced ? p.rows_cap : p.rows_per_chunk));
+    snprintf(p.main_kernel, sizeof(p.main_kernel), "light_rows_window_kernel");
 }
 
 #endif  // MI355_TU_F64
@@ -291,10 +296,14 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
             hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, TT, R, 0, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
         break;
     if constexpr (BLOCK == kBlock) if (p.balanced) {   // vector width per chunk (chunk_rows_any); the T of the template is not used
-        if (p.window_elems > 0)
+        // (the weight-cut layout holds up to 2 K rows of 64-bit bounds and fp64 results next to the window: past 64 KB)
+        if (p.window_elems > 0) {
+            if (const int st = allow_dynamic_lds((const void*)light_rows_window_kernel<BLOCK, 2, R, 1, true, off_t, val_t>, lds)) return st;
             hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, 2, R, 1, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);
-        else
+        } else {
+            if (const int st = allow_dynamic_lds((const void*)light_rows_window_kernel<BLOCK, 2, R, 0, true, off_t, val_t>, lds)) return st;
             hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, 2, R, 0, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);
+        }
         MI355_HIP_TRY(hipGetLastError());
         return launch_giant_rows<off_t, val_t>(p, Ap, Ax, x, y, s);   // (rows too long for one workgroup, if any)
     }

@@ -91,17 +91,20 @@ template <typename val_t> struct Semiring<MI355_SEMIRING_MAX_TIMES, val_t> {
 // (L = 1 is the bisection); launch_merge picks L from the measured crossovers.
 template <int kSearchLanes, typename off_t>
 __global__ __launch_bounds__(kBlock) void merge_search_kernel(
-    int32_t n_rows, int64_t nnz, const off_t* __restrict__ Ap, int64_t tile_items, int64_t n_tiles,
+    int32_t n_rows, int64_t nnz_begin, int64_t nnz, const off_t* __restrict__ Ap, int64_t tile_items, int64_t n_tiles,
     int32_t* __restrict__ tile_row, int64_t* __restrict__ tile_nnz) {
+    // (nnz_begin = Ap[0], nnz = Ap[n_rows]: the counting sequence of the merge is nnz_begin .. nnz - 1; a
+    // row-block view of a larger CSR starts at 1..3, everything else at 0)
     const int64_t gid = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     const int64_t t_raw = gid / kSearchLanes;
     const int64_t t = t_raw <= n_tiles ? t_raw : n_tiles;       // surplus groups repeat the last diagonal
     const int k = int(gid) & (kSearchLanes - 1);
     const int shift = (threadIdx.x & (kWave - 1)) & ~(kSearchLanes - 1);
-    const int64_t items = int64_t(n_rows) + nnz;
+    const int64_t count = nnz - nnz_begin;
+    const int64_t items = int64_t(n_rows) + count;
     int64_t diag = t * tile_items;
     if (diag > items) diag = items;
-    int64_t lo = diag - nnz > 0 ? diag - nnz : 0;
+    int64_t lo = diag - count > 0 ? diag - count : 0;
     int64_t hi = diag < n_rows ? diag : n_rows;
     while (__any(lo < hi)) {                                    // a finished group probes nothing new: c = 0
         const int64_t n = hi - lo;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void merge_search_kernel(
         auto probe = [&](int j) { return last ? lo + j : lo + (int64_t(j + 1) * n) / (kSearchLanes + 1); };
         const int64_t q = probe(k);
         const int64_t qc = q < hi ? q : hi - 1;                 // clamped into [-1, n_rows): the load is in range
-        const bool below = (q < hi) & (int64_t(Ap[qc + 1]) <= diag - qc - 1);
+        const bool below = (q < hi) & (int64_t(Ap[qc + 1]) - nnz_begin <= diag - qc - 1);
         const int c = __popcll((__ballot(below) >> shift) & ((1ull << kSearchLanes) - 1));
         if (last) {
             lo += c;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void merge_search_kernel(
     }
     if (k == 0 && t_raw <= n_tiles) {
         tile_row[t] = int32_t(lo);
-        tile_nnz[t] = diag - lo;
+        tile_nnz[t] = nnz_begin + diag - lo;
     }
 }
 
@@ -397,26 +400,21 @@ __global__ __launch_bounds__(kBlock) void merge_fixup_kernel(
 }
 
 // ---- host side -----------------------------------------------------------------------
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 void shape_merge(Plan& p) {
     // tuning knobs: MI355_MERGE_TPS = tiles per run (and MI355_SPMV_WINDOW = 0|1, analyze.hip)
     // 256 threads x 8 items or (MI355_MERGE_BLOCK=512) 512 threads x 4 items: the same 2 044-item tiles
-    p.block_threads = env_int("MI355_MERGE_BLOCK", kBlock) == kWideBlock ? kWideBlock : kBlock;
+    p.block_threads = p.knob.merge_block == kWideBlock ? kWideBlock : kBlock;
     const int ipt = p.block_threads == kWideBlock ? 4 : 8;   // (16 measured no better)
     p.lanes_per_row = 0;
     p.elems_per_lane = ipt;            // reported as items per thread for this kind
     p.tile_items = int64_t(p.block_threads) * ipt - 4;
-    const int64_t items = int64_t(p.n_rows) + p.nnz;
+    const int64_t items = int64_t(p.n_rows) + (p.nnz - p.nnz_begin);
     p.n_tiles = (items + p.tile_items - 1) / p.tile_items;
     // runs of up to ~32 K items, but at least ~4 runs per CU when the matrix allows
     int64_t tps = p.n_tiles / (int64_t(kCus) * 4);
     const int64_t cap = kMergeSuperItems / p.tile_items;
     if (tps > cap) tps = cap;
-    tps = env_int("MI355_MERGE_TPS", int(tps));
+    if (p.knob.merge_tps > 0) tps = p.knob.merge_tps;
     if (tps < 1) tps = 1;
     p.tiles_per_super = tps;
     p.n_super = (p.n_tiles + tps - 1) / tps;
@@ -424,7 +422,7 @@ void shape_merge(Plan& p) {
     // a window of x only pays when a run is long enough to amortise staging it, and
     // when the band the probe saw (plus the rows of a run) fits
     {
-        const int64_t mean1 = 1 + (p.n_rows > 0 ? p.nnz / p.n_rows : 0);
+        const int64_t mean1 = 1 + (p.n_rows > 0 ? (p.nnz - p.nnz_begin) / p.n_rows : 0);
         const int64_t rows_per_run = tps * p.tile_items / mean1 + 1;
         p.window_elems = (tps * p.tile_items >= 8192) ? pick_window_elems(p, rows_per_run) : 0;
         if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }   // several bands: this kind keeps to global gathers
@@ -443,17 +441,17 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
     if (!reuse) {
         const int64_t diagonals = p.n_tiles + 1;
         // measured (us, L = 1 / 4 / 16): 2 946 diagonals 7.3 / 6.0 / 4.4, 68 K 11.9 / 8.5 / 13.3, 139 K 14.0 / 16.0 / 30.9
-        static const int forced = env_int("MI355_MERGE_SEARCH_LANES", 0);
+        const int forced = p.knob.merge_search_lanes;
         const int lanes = forced > 0 ? forced : diagonals <= 16384 ? 16 : diagonals <= 98304 ? 4 : 1;
         const unsigned g = unsigned((diagonals * lanes + kBlock - 1) / kBlock);
         if (lanes >= 16)
-            hipLaunchKernelGGL((merge_search_kernel<16, off_t>), dim3(g), dim3(kBlock), 0, s, p.n_rows, p.nnz, Ap,
+            hipLaunchKernelGGL((merge_search_kernel<16, off_t>), dim3(g), dim3(kBlock), 0, s, p.n_rows, p.nnz_begin, p.nnz, Ap,
                                p.tile_items, p.n_tiles, p.tile_row, p.tile_nnz);
         else if (lanes >= 4)
-            hipLaunchKernelGGL((merge_search_kernel<4, off_t>), dim3(g), dim3(kBlock), 0, s, p.n_rows, p.nnz, Ap,
+            hipLaunchKernelGGL((merge_search_kernel<4, off_t>), dim3(g), dim3(kBlock), 0, s, p.n_rows, p.nnz_begin, p.nnz, Ap,
                                p.tile_items, p.n_tiles, p.tile_row, p.tile_nnz);
         else
-            hipLaunchKernelGGL((merge_search_kernel<1, off_t>), dim3(g), dim3(kBlock), 0, s, p.n_rows, p.nnz, Ap,
+            hipLaunchKernelGGL((merge_search_kernel<1, off_t>), dim3(g), dim3(kBlock), 0, s, p.n_rows, p.nnz_begin, p.nnz, Ap,
                                p.tile_items, p.n_tiles, p.tile_row, p.tile_nnz);
         MI355_HIP_TRY(hipGetLastError());
         p.coords_valid = true;

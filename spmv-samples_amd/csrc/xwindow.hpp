@@ -442,7 +442,10 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
         bool more = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            deferred[r] = (G.b[r + 1] - G.b[r]) > LONG;    // uniform over the T lanes of the vector
+            // (uniform over the T lanes of the vector; a giant row always takes the long-row path, where it is
+            // zeroed for the slice kernels, whatever the long-steps knob says)
+            const off_t len_r = G.b[r + 1] - G.b[r];
+            deferred[r] = len_r > LONG || (scr.giant_len > 0 && int64_t(len_r) > scr.giant_len);
             // the 16-byte path covers elements below nnz_vec; a long row is left to pass 2
             hi[r] = deferred[r] ? G.b[r] : (G.b[r + 1] < nnz_vec ? G.b[r + 1] : nnz_vec);
             sum[r] = val_t(0);

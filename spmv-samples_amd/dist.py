@@ -19,12 +19,32 @@ import torch
 import torch.distributed as dist
 
 
-def partition_rows(Ap, parts, balance="nnz"):
+def partition_rows(Ap, parts, balance="nnz", unit=None, table=None):
     """Cut points r_0=0 <= r_1 <= ... <= r_P=n_rows.
-    balance="nnz": Ap[r_p] ~ p*nnz/P;  "rows": equal row counts."""
+    balance="nnz": Ap[r_p] ~ p*nnz/P;  "rows": equal row counts.
+    unit / table: the rule of the library's mi355_spmv_plan_partition (csrc/analyze.hip, partition_kernel),
+    restated with torch so that it also runs on the CPU: a cut may only fall on a UNIT boundary — row
+    u * unit (uniform chunks of `unit` rows; 4 for the merge kind), or table[u] (the chunk table of a
+    weight-cut plan) — and cut p is the first unit whose first row starts at or after nonzero
+    Ap[0] + (Ap[n] - Ap[0]) * p // P.  Blocks then own whole chunks of the whole matrix's plan."""
     n_rows = Ap.numel() - 1
     if balance == "rows":
         return [n_rows * p // parts for p in range(parts + 1)]
+    if unit is not None or table is not None:
+        if table is not None:
+            rows = torch.as_tensor(table, dtype=torch.int64, device=Ap.device)
+        else:
+            n_units = (n_rows + unit - 1) // unit
+            rows = torch.clamp(torch.arange(n_units + 1, dtype=torch.int64, device=Ap.device) * unit, max=n_rows)
+        starts = Ap.to(torch.int64)[rows]                     # Ap at every unit boundary (ascending)
+        first, last = int(Ap[0].item()), int(Ap[-1].item())
+        targets = torch.tensor([first + (last - first) * p // parts for p in range(1, parts)], dtype=torch.int64,
+                               device=Ap.device)
+        u = torch.searchsorted(starts.contiguous(), targets, right=False).clamp_(max=rows.numel() - 1)
+        cuts = [0] + rows[u].tolist() + [n_rows] if parts > 1 else [0, n_rows]
+        for i in range(1, len(cuts)):
+            cuts[i] = max(cuts[i], cuts[i - 1])
+        return cuts
     nnz = int(Ap[-1].item())
     targets = torch.tensor([nnz * p // parts for p in range(1, parts)], dtype=Ap.dtype, device=Ap.device)
     mid = torch.searchsorted(Ap.contiguous(), targets, right=False).tolist() if parts > 1 else []
@@ -42,6 +62,18 @@ def shard_csr(Ap, Aj, Ax, r0, r1):
     # .clone(): a fresh allocation is 256-byte aligned, which the 16-byte-per-lane
     # loads of the kernels rely on (an offset view of the parent array is not)
     return Ap_l, Aj[lo:hi].clone(), Ax[lo:hi].clone()
+
+
+def block_view(Ap, Aj, Ax, r0, r1):
+    """Rows [r0, r1) as a 16-byte-aligned VIEW of the parent arrays — the form
+    mi355_spmv_plan_create_block / mi355_spmv_dist_create_rank take: Aj / Ax start at element
+    lo = Ap[r0] & ~3 (no copy), Ap_l[i] = Ap[r0 + i] - lo, so Ap_l[0] is the block's phase (0..3) and
+    Ap_l[-1] the END offset.  Every row keeps the position it has in the parent modulo 4, which is what
+    the 16-byte sweeps of the row-local kernels sum by.  Returns (Ap_l, Aj_view, Ax_view, lo)."""
+    lo = int(Ap[r0].item()) & ~3
+    hi = int(Ap[r1].item())
+    Ap_l = (Ap[r0:r1 + 1] - lo).contiguous()
+    return Ap_l, Aj[lo:hi], Ax[lo:hi], lo
 
 
 class _Works:

@@ -305,7 +305,7 @@ coo_t<index_t, offset_t, value_t> LoadCoo(std::string filename) {
     });
     for (size_t c = 0; c < n_chunks; ++c) tok_begin[c + 1] += tok_begin[c];
 
-    std::vector<int> status(n_chunks, 0);   // 0 ok, 1 short read, 2 zero index
+    std::vector<int> status(n_chunks, 0);   // 0 ok, 1 short read, 2 zero index, 3 index beyond the header's size
     for_chunks([&](size_t c) {
         const char* q = body + c * chunk;
         const char* e = std::min(q + chunk, end);
@@ -326,6 +326,9 @@ coo_t<index_t, offset_t, value_t> LoadCoo(std::string filename) {
             if (ok && !pattern) ok = parse_lf(q, end, w);
             if (!ok) { status[c] = 1; return; }
             if (r == 0 || cidx == 0) { status[c] = 2; return; }
+            // The reference does not look (load.hpp:329-343 there) and then indexes out of bounds in ToCsr and,
+            // through x[column], on the device: a file that passes here behaves exactly as it does there.
+            if (r > n_rows || cidx > n_cols) { status[c] = 3; return; }
             coo.row_indices[entry] = index_t(r) - 1;
             coo.column_indices[entry] = index_t(cidx) - 1;
             coo.nonzero_values[entry] = pattern ? value_t(1.0) : value_t(w);
@@ -340,6 +343,7 @@ coo_t<index_t, offset_t, value_t> LoadCoo(std::string filename) {
     for (size_t c = 0; c < n_chunks; ++c) {
         if (status[c] == 1) throw exception_t(short_msg);
         if (status[c] == 2) throw exception_t("Market file is zero-indexed");
+        if (status[c] == 3) throw exception_t("Market file has an index beyond its declared size");
     }
     throw_if_exception(total_tokens / tokens_per_entry < n_entries, short_msg);
 

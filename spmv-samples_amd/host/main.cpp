@@ -26,6 +26,8 @@
 //                    that skips rows looks correct
 //   --unit-us        label the time columns "us": the reference prints microseconds under
 //                    an "ms" label (timer.hpp:10 vs main.cu:111-112); default keeps its label
+//   --ngpu N         GPUs the hip_dist_* kinds spread the rows over (default 1; the reference is
+//                    single-device, main.cu:53); --sub-blocks S = row blocks per GPU (default 4 when N > 1)
 #include <hip/hip_runtime_api.h>
 
 #include <cmath>
@@ -114,6 +116,7 @@ static int run(const char* path, const std::vector<std::string>& kinds, const Op
             std::printf("[%-12s] total: %12lf ms  kernel: %12lf ms\n", kind.data(), 1. * total_time / opt.iters,
                         1. * kernel_time / opt.iters);
     }
+    mi355_host::dist_release();   // (the multi-GPU kinds keep their handle between calls)
     checkHipErr(hipFree(dAp)); checkHipErr(hipFree(dAj)); checkHipErr(hipFree(dAx));
     checkHipErr(hipFree(dX)); checkHipErr(hipFree(dY));
     return EXIT_SUCCESS;
@@ -132,6 +135,8 @@ int main(int argc, char** argv) {
         if (a == "--iters") opt.iters = std::max(1, std::atoi(value("--iters").c_str()));
         else if (a == "--dtype") dtype = value("--dtype");
         else if (a == "--offset") offset = value("--offset");
+        else if (a == "--ngpu") mi355_host::dist_gpus() = std::max(1, std::atoi(value("--ngpu").c_str()));
+        else if (a == "--sub-blocks") mi355_host::dist_sub_blocks() = std::max(1, std::atoi(value("--sub-blocks").c_str()));
         else if (a == "--no-poison") opt.poison = false;
         else if (a == "--unit-us") opt.unit_us = true;
         else kinds.push_back(a);

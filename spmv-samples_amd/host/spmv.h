@@ -39,6 +39,9 @@
     X("hip_merge", SpMV_hip_merge)                    \
     X("hip_light", SpMV_hip_light)                    \
     X("hip_merge_genl", SpMV_hip_merge_generalized)   \
+    X("hip_dist_vector", SpMV_hip_dist_vector)        \
+    X("hip_dist_merge", SpMV_hip_dist_merge)          \
+    X("hip_dist_light", SpMV_hip_dist_light)          \
     SPMV_KINDS_VENDOR
 
 template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,

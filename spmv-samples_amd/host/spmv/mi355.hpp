@@ -73,6 +73,71 @@ void run_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const offs
     MI355_CHECK(mi355_spmv_plan_destroy(plan));
 }
 
+// ---- multi-GPU kinds (SURVEY §8(b) last row, §8(e)): "a separate kind/entry that owns its per-device
+// plans and RCCL communicator".  The reference is single-device (main.cu:53, common.cuh:8); these kinds take
+// the same 8 arguments — device arrays on the CURRENT device — and spread the rows over dist_gpus() GPUs of
+// the node through mi355_spmv_dist_* (LOCAL mode: this one host thread drives every GPU).  Unlike the
+// single-GPU kinds they keep their handle between calls (cutting the matrix and copying the blocks to the
+// other GPUs per call would dwarf the SpMV): the handle is rebuilt when the structure arrays or sizes
+// change, the values are re-scattered when the Ax pointer changes (a caller that rewrites Ax in place calls
+// dist_release()), x is re-replicated on EVERY call, as SpMV(kind, ...) hands over a fresh x each time.
+inline int& dist_gpus() {
+    static int n = [] { const char* e = std::getenv("MI355_NGPU"); const int v = e ? std::atoi(e) : 1; return v > 0 ? v : 1; }();
+    return n;
+}
+inline int& dist_sub_blocks() {
+    static int n = [] { const char* e = std::getenv("MI355_SUB_BLOCKS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();
+    return n;
+}
+struct DistCache {
+    mi355_spmv_dist* d = nullptr;
+    int kind = -1, off_type = -1, val_type = -1, gpus = 0, sub = 0;
+    long long n_rows = -1, n_cols = -1, nnz = -1;
+    const void *Ap = nullptr, *Aj = nullptr, *Ax = nullptr;
+};
+inline DistCache& dist_cache() { static DistCache c; return c; }
+inline void dist_release() {
+    DistCache& c = dist_cache();
+    if (c.d) MI355_CHECK(mi355_spmv_dist_destroy(c.d));
+    c = DistCache();
+}
+
+template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,
+          typename vec_y_value_t>
+void run_dist_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap, const index_t* Aj,
+                   const mat_value_t* Ax, const vec_x_value_t* x, vec_y_value_t* y) {
+    static_assert(std::is_same<index_t, int>::value || std::is_same<index_t, int32_t>::value,
+                  "mi355 kinds: index_t must be a 32-bit int (reference main.cu:15)");
+    static_assert(std::is_integral<offset_t>::value && std::is_signed<offset_t>::value && (sizeof(offset_t) == 4 || sizeof(offset_t) == 8),
+                  "mi355 kinds: offset_t must be a signed 32- or 64-bit integer");
+    static_assert(std::is_same<mat_value_t, vec_x_value_t>::value && std::is_same<mat_value_t, vec_y_value_t>::value,
+                  "mi355 multi-GPU kinds: A, x and y share one value type");
+    static_assert(std::is_same<mat_value_t, float>::value || std::is_same<mat_value_t, double>::value,
+                  "mi355 kinds: value type is float or double");
+    const int off_type = sizeof(offset_t) == 8 ? MI355_OFF_I64 : MI355_OFF_I32;
+    const int val_type = std::is_same<mat_value_t, double>::value ? MI355_VAL_F64 : MI355_VAL_F32;
+    const int gpus = dist_gpus();
+    const int sub = dist_sub_blocks() > 0 ? dist_sub_blocks() : (gpus > 1 ? 4 : 1);
+    DistCache& c = dist_cache();
+    const bool same = c.d && c.kind == kind && c.off_type == off_type && c.val_type == val_type && c.gpus == gpus &&
+                      c.sub == sub && c.n_rows == (long long)n_rows && c.n_cols == (long long)n_cols &&
+                      c.nnz == (long long)nnz && c.Ap == Ap && c.Aj == Aj;
+    if (!same) {
+        dist_release();
+        MI355_CHECK(mi355_spmv_dist_create_local(&c.d, kind, off_type, val_type, (int32_t)n_rows, (int32_t)n_cols,
+                                                 (int64_t)nnz, Ap, reinterpret_cast<const int32_t*>(Aj), gpus,
+                                                 /*devices=*/nullptr, sub, MI355_PLAN_DEFAULT));
+        c.kind = kind; c.off_type = off_type; c.val_type = val_type; c.gpus = gpus; c.sub = sub;
+        c.n_rows = n_rows; c.n_cols = n_cols; c.nnz = nnz; c.Ap = Ap; c.Aj = Aj; c.Ax = nullptr;
+    }
+    const void* ax = (gpus > 1 && c.Ax == Ax) ? nullptr : Ax;   // NULL = the other GPUs already hold these values
+    Timer::kernel_start();
+    MI355_CHECK(mi355_spmv_dist_execute(c.d, ax, x, y, /*stream=*/nullptr));
+    MI355_CHECK(mi355_spmv_stream_synchronize(/*stream=*/nullptr));
+    Timer::kernel_stop();
+    c.Ax = Ax;
+}
+
 }  // namespace mi355_host
 
 #define MI355_DEFINE_KIND(NAME, KIND)                                                                          \
@@ -89,6 +154,18 @@ MI355_DEFINE_KIND(SpMV_hip_vector, MI355_KIND_VECTOR)
 MI355_DEFINE_KIND(SpMV_hip_merge, MI355_KIND_MERGE)
 /// LightSpMV-style dynamic row distribution (sharded atomic row counters)
 MI355_DEFINE_KIND(SpMV_hip_light, MI355_KIND_LIGHT)
+
+#define MI355_DEFINE_DIST_KIND(NAME, KIND)                                                                     \
+    template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,               \
+              typename vec_y_value_t>                                                                          \
+    void NAME(index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap, const index_t* Aj,             \
+              const mat_value_t* Ax, const vec_x_value_t* x, vec_y_value_t* y) {                               \
+        ::mi355_host::run_dist_kind(KIND, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);                              \
+    }
+/// the same three kinds over mi355_host::dist_gpus() GPUs: row blocks, x replicated, allgatherv(y) over RCCL
+MI355_DEFINE_DIST_KIND(SpMV_hip_dist_vector, MI355_KIND_VECTOR)
+MI355_DEFINE_DIST_KIND(SpMV_hip_dist_merge, MI355_KIND_MERGE)
+MI355_DEFINE_DIST_KIND(SpMV_hip_dist_light, MI355_KIND_LIGHT)
 
 /// generalized merge-path SpMV (cf. SpMV_merge_based_generalized, merge_genl.cuh:41-79);
 /// functor_t is one of mi355_host::PlusTimes (default, the reference's MergeFunctor), MinPlus, MaxTimes

@@ -73,9 +73,10 @@ def random_csr(rng, n_rows, n_cols, max_len, off_dtype=np.int32, val_dtype=np.fl
     return Ap.astype(off_dtype), Aj, Ax
 
 
-def parity_bound(oracle, Ap, Aj, Ax, x):
-    """Per-row bound of SURVEY.md §8(c): (len+2) * eps * sum|a*x| around the fp64 serial sum."""
-    y64, yabs = oracle.spmv_ref64(Ap, Aj, Ax, x)
+def parity_bound(oracle, Ap, Aj, Ax, x, n_threads=1):
+    """Per-row bound of SURVEY.md §8(c): (len+2) * eps * sum|a*x| around the fp64 serial sum.
+    n_threads splits the rows of the oracle pass over host threads (same values)."""
+    y64, yabs = oracle.spmv_ref64(Ap, Aj, Ax, x, n_threads)
     eps = 2.0 ** -24 if Ax.dtype == np.float32 else 2.0 ** -53
     lens = np.diff(Ap.astype(np.int64))
     return y64, (lens + 2) * eps * yabs

@@ -103,6 +103,7 @@ static int run_combo(const char* combo, int n_rows, int n_cols, int max_len) {
     }
     SPMV_KINDS
 #undef X
+    mi355_host::dist_release();   // the multi-GPU kinds keep a handle on dAp / dAj between calls
     HIP_OK(hipFree(dAp)); HIP_OK(hipFree(dAj)); HIP_OK(hipFree(dAx)); HIP_OK(hipFree(dX)); HIP_OK(hipFree(dY));
     return failures;
 }
@@ -116,6 +117,7 @@ int main(int argc, char** argv) {
         return 0;  // not reached: SpMV exits with EXIT_FAILURE
     }
     int failures = 0;
+    mi355_host::dist_sub_blocks() = 3;   // hip_dist_*: one GPU here, its rows in three blocks
     failures += run_combo<int, float>("i32_f32", 3001, 2500, 24);
     failures += run_combo<int, double>("i32_f64", 3001, 2500, 24);
     failures += run_combo<long long, float>("i64_f32", 3001, 2500, 24);

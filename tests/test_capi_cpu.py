@@ -14,7 +14,7 @@ from conftest import ROOT
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "mi355_spmv.h")).read()
     names = set(re.findall(r"\b(mi355_spmv_[a-z_0-9]+)\s*\(", text))
-    names.discard("mi355_spmv_plan")
+    names -= {"mi355_spmv_plan", "mi355_spmv_dist", "mi355_spmv_plan_shape", "mi355_spmv_plan_info"}
     # the one-shot family is declared through a macro
     for kind in re.findall(r"MI355_SPMV_DECLARE_KIND\((\w+)\)", text):
         if kind == "KIND":
@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(sp):
 
 def test_version_and_status_strings(sp):
     lib = sp.capi.lib()
-    assert lib.mi355_spmv_version() == 100
+    assert lib.mi355_spmv_version() == 200
     assert lib.mi355_spmv_status_string(0) == b"ok"
     assert lib.mi355_spmv_status_string(1) == b"invalid argument"
     assert lib.mi355_spmv_status_string(99) == b"unknown status"
@@ -66,6 +66,27 @@ def test_plan_create_rejects_bad_arguments_without_touching_the_device(sp):
         assert lib.mi355_spmv_last_error() != b""
     assert lib.mi355_spmv_plan_execute(None, None, None, None, None) == 1
     assert lib.mi355_spmv_plan_destroy(None) == 0
+
+
+def test_dist_entry_points_reject_bad_arguments_without_touching_the_device(sp):
+    """The multi-GPU entry points (include/mi355_spmv.h, mi355_spmv_dist_*) check their arguments before
+    any device or RCCL call."""
+    lib = sp.capi.lib()
+    h = C.c_void_p()
+    dummy = C.c_void_p(256)
+    assert lib.mi355_spmv_dist_create_local(C.byref(h), 0, 0, 0, 4, 4, 4, dummy, dummy, 0, None, 1, 0) == 1   # no devices
+    assert lib.mi355_spmv_dist_create_local(C.byref(h), 0, 0, 0, 4, 4, 4, dummy, dummy, 1, None, 0, 0) == 1   # no sub-blocks
+    assert lib.mi355_spmv_dist_create_local(None, 0, 0, 0, 4, 4, 4, dummy, dummy, 1, None, 1, 0) == 1
+    cuts = (C.c_int64 * 3)(0, 4, 8)
+    assert lib.mi355_spmv_dist_create_rank(C.byref(h), 0, 0, 0, 2, 2, None, 1, cuts, cuts, cuts, None, 4, 4, 4,
+                                           dummy, dummy, 0) == 1                                              # rank >= world
+    assert lib.mi355_spmv_dist_create_rank(C.byref(h), 0, 0, 0, 0, 2, None, 1, cuts, cuts, cuts, None, 4, 4, 4,
+                                           dummy, dummy, 0) == 1                                              # world 2, no id
+    assert not h.value
+    assert lib.mi355_spmv_dist_execute(None, None, None, None, None) == 1
+    assert lib.mi355_spmv_dist_destroy(None) == 0
+    assert lib.mi355_spmv_dist_parts(None) == 0
+    assert lib.mi355_spmv_knobs_reload() == 0
 
 
 def test_binding_refuses_host_tensors_and_unknown_kinds(sp):

@@ -1,7 +1,7 @@
 """CPU suite, part 4: the N>1 path (row partition, shard, allgatherv) with gloo, world_size 2.
 The per-rank SpMV here is the ORACLE (test infrastructure standing in for the GPU
-kernel, which cannot run in this container); tests/test_gpu_dist.py runs the same
-flow with the HIP path."""
+kernel, which cannot run in this container); tests/test_gpu_host.py and
+tests/test_gpu_configs.py run the same flow with the HIP path (mi355_spmv_dist_*)."""
 import os
 import socket
 
@@ -26,6 +26,49 @@ def test_partition_rows_balances_nnz(sp):
     left = int(Ap[cuts[1]])
     assert abs(left - Ap[-1] / 2) <= 30000                          # within one (long) row of the target
     assert sp.dist.partition_rows(Ap_t, 4, balance="rows") == [0, 250, 500, 750, 1000]
+
+
+def test_partition_on_unit_boundaries(sp):
+    """The library's cut rule (mi355_spmv_plan_partition), restated in dist.partition_rows: cuts fall on
+    chunk boundaries only, each is the first boundary at or after its nonzero target."""
+    rng = np.random.RandomState(3)
+    Ap, _, _ = random_csr(rng, 1003, 50, 20, long_row=9000)
+    Ap_t = torch.from_numpy(Ap)
+    for unit in (4, 64, 1000):
+        for parts in (2, 3, 8):
+            cuts = sp.dist.partition_rows(Ap_t, parts, unit=unit)
+            assert cuts[0] == 0 and cuts[-1] == 1003 and len(cuts) == parts + 1
+            assert all(a <= b for a, b in zip(cuts, cuts[1:]))
+            for p in range(1, parts):
+                c = cuts[p]
+                assert c % unit == 0 or c == 1003
+                target = int(Ap[-1]) * p // parts
+                assert Ap[c] >= target or c == 1003
+                assert c == 0 or Ap[max(c - unit, 0)] < target or cuts[p - 1] == c
+    table = [0, 8, 8, 200, 640, 1003]                               # a weight-cut plan's table (an empty chunk too)
+    cuts = sp.dist.partition_rows(Ap_t, 3, table=table)
+    assert all(c in table for c in cuts) and cuts[0] == 0 and cuts[-1] == 1003
+
+
+def test_block_view_keeps_the_16_byte_phase(sp, oracle):
+    """block_view: no copy of Aj / Ax, Ap_l[0] = the first row's position modulo 4, and the rows of the
+    view are the rows of the parent."""
+    rng = np.random.RandomState(4)
+    Ap, Aj, Ax = random_csr(rng, 300, 90, 17)
+    Ap_t, Aj_t, Ax_t = map(torch.from_numpy, (Ap, Aj, Ax))
+    x = (rng.rand(90) * 2 - 1).astype(np.float32)
+    y = oracle.spmv_serial(Ap, Aj, Ax, x)
+    for r0, r1 in ((0, 300), (4, 120), (120, 300), (296, 300), (300, 300)):
+        a, j, v, lo = sp.dist.block_view(Ap_t, Aj_t, Ax_t, r0, r1)
+        assert lo % 4 == 0 and int(a[0]) == int(Ap[r0]) - lo and 0 <= int(a[0]) <= 3
+        if j.numel():
+            assert j.data_ptr() == Aj_t.data_ptr() + 4 * lo and v.data_ptr() == Ax_t.data_ptr() + 4 * lo
+        assert int(a[-1]) == j.numel() == v.numel()
+        for i in range(r1 - r0):
+            s, e = int(a[i]), int(a[i + 1])
+            assert np.array_equal(j[s:e].numpy(), Aj[Ap[r0 + i]:Ap[r0 + i + 1]])
+        # the oracle's serial loop takes any Ap[0]
+        assert np.array_equal(oracle.spmv_serial(a.numpy(), j.numpy(), v.numpy(), x), y[r0:r1])
 
 
 def test_shard_csr_is_a_standalone_matrix(sp, oracle):

@@ -29,7 +29,8 @@ def test_cpp_boundary_all_labels_and_types():
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ALL PASSED" in r.stdout
-    for label in ("hip_vector", "hip_merge", "hip_light", "hip_merge_genl"):
+    for label in ("hip_vector", "hip_merge", "hip_light", "hip_merge_genl", "hip_dist_vector", "hip_dist_merge",
+                  "hip_dist_light"):
         assert r.stdout.count("[%-14s]" % label) == 4
 
 

@@ -381,6 +381,38 @@ def test_giant_rows_are_split_across_workgroups(sp, oracle, off):
 
 
 @pytest.mark.parametrize("kind", ["vector", "light"])
+def test_weight_cut_chunks_with_a_band_window_in_fp64_i64(sp, oracle, kind):
+    """A banded fp64 matrix with 64-bit offsets and a few dense rows: the plan cuts chunks by weight AND stages
+    a band-placed window of x; the workgroup's LDS layout (2 052 rows of 8-byte bounds and results + the
+    window) passes the default 64 KB, so the launch has to raise the kernel's limit first (a launch that
+    does not returns an error: this case used to be untested)."""
+    rng = np.random.RandomState(77)
+    n = 1_200_000
+    lens = np.full(n, 20, dtype=np.int64)
+    hubs = rng.choice(n, size=40, replace=False)
+    lens[hubs] = 30_000
+    Ap = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=Ap[1:])
+    nnz = int(Ap[-1])
+    rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+    Aj = np.clip(rows + rng.randint(-1500, 1501, size=nnz), 0, n - 1).astype(np.int32)
+    del rows
+    Ax = (rng.rand(nnz) * 2 - 1)
+    x = (rng.rand(n) * 2 - 1)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    dAp, dAj, dAx, dx = d(Ap), d(Aj), d(Ax), d(x)
+    p = sp.Plan(kind, n, n, nnz, dAp, dAj, torch.float64)
+    info = p.info()
+    if not any(k.startswith("MI355_SPMV_") for k in os.environ if k != "MI355_SPMV_LIB"):   # (no forced code path)
+        assert info["balanced_chunks"] == 1 and info["window_elems"] > 0, info
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device=DEV)
+    p.execute(dAx, dx, y)
+    torch.cuda.synchronize()
+    p.destroy()
+    assert_parity(oracle, Ap, Aj, Ax, x, y.cpu().numpy())
+
+
+@pytest.mark.parametrize("kind", ["vector", "light"])
 def test_wide_band_fp64_takes_more_than_64_kb_of_lds(sp, oracle, kind):
     """The S32-band shape in fp64 (band of 8 193 columns = 64 KB of doubles): the window only fits when the
     workgroup takes more than the default 64 KB of LDS (two 512-thread workgroups of ~78 KB per CU).  Every

@@ -111,6 +111,10 @@ def test_product_loader_matches_oracle_and_reference_on_generated_files(hostlib,
     ("%%MatrixMarket matrix coordinate real general\n2 2 1\n0 1 1.0\n", "entry"),   # zero-based index
     ("%%MatrixMarket matrix coordinate pattern general\n2 2 2\n1 1\n2 x\n", "entry"),
     ("%%MatrixMarket matrix coordinate real general\n2147483647 1 0\n", "overflow"),
+    # an index beyond the header's size: the reference does not look and then writes past row_offsets in ToCsr
+    # (and a column beyond n_cols becomes x[col] on the device); the product loader refuses the file
+    ("%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 1.0\n3 1 2.0\n", "entry"),
+    ("%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 1.0\n2 5 2.0\n", "entry"),
 ])
 def test_product_loader_exceptions(hostlib, tmp_path, text, err):
     """Malformed entries / overflow throw exception_t like the reference (load.hpp:302-306, :324-351)."""

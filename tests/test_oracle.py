@@ -198,3 +198,14 @@ def test_generalized_serial_matches_reference_build(oracle, ref, semiring, off, 
     assert np.all(got[empty] == ident)                       # an empty row yields initialize()
     if semiring == 0:
         assert np.array_equal(got, oracle.spmv_serial(Ap, Aj, Ax, x))
+
+
+def test_ref64_threads_do_not_change_values(oracle):
+    """The threaded pass used by the BASELINE-sized GPU tests splits ROWS only."""
+    rng = np.random.RandomState(5)
+    Ap, Aj, Ax = random_csr(rng, 5003, 700, 40, np.int64, np.float64, long_row=9000)
+    x = (rng.rand(700) * 2 - 1).astype(np.float64)
+    a = oracle.spmv_ref64(Ap, Aj, Ax, x)
+    for t in (2, 7, 16):
+        b = oracle.spmv_ref64(Ap, Aj, Ax, x, t)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
