@@ -185,7 +185,10 @@ int mi355_spmv_plan_get_info(const mi355_spmv_plan* plan, mi355_spmv_plan_info* 
  *                               Aj / Ax start at element (Ap_whole[row_begin] & ~3) and Ap[i] =
  *                               Ap_whole[row_begin + i] - (Ap_whole[row_begin] & ~3), so Ap[0] is 0..3 (the
  *                               "phase") and nnz is the END offset Ap[n_rows].  No copy of Aj / Ax is needed on
- *                               the device that holds the whole matrix.
+ *                               the device that holds the whole matrix.  Unless the block ends where the whole
+ *                               matrix ends, Aj / Ax must be READABLE up to the next multiple of 4 elements
+ *                               past nnz (a view of the whole arrays is; a copy is padded): the tail of the
+ *                               block's last row is then read in whole 16-byte groups, as the whole plan does.
  * MERGE blocks take the same arrays but are shaped on their own (tile boundaries move with the cut anyway;
  * results stay inside the parity bound); shape may then be NULL.                              */
 typedef struct mi355_spmv_plan_shape {

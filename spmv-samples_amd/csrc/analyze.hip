@@ -53,6 +53,7 @@ static void parse_knobs(Knobs& k) {
     geti("MI355_SPMV_GIANT", k.giant);
     getl("MI355_SPMV_GIANT_ROW", k.giant_row);
     geti("MI355_SPMV_PLAIN", k.plain);
+    getl("MI355_SPMV_REL32_LIMIT", k.rel32_limit);
     geti("MI355_LIGHT_BLOCKS_PER_CU", k.light_blocks_per_cu);
     geti("MI355_LIGHT_CHUNK_DIV", k.light_chunk_div);
     geti("MI355_MERGE_BLOCK", k.merge_block);
@@ -243,6 +244,15 @@ int allow_dynamic_lds(const void* kernel, size_t bytes) {
     MI355_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
     have = bytes;
     return MI355_SPMV_OK;
+}
+
+// Workgroups of the plan's size a CU holds by REGISTERS (the launch bounds of the VECTOR / LIGHT kernels): two of
+// 512 threads; four of 256 when the body keeps 2 rows per vector in flight (fp64; fp32 with 16+ lanes per row),
+// three with 4 rows (fp32, up to 8 lanes per row, and the per-chunk-width kernels of weight-cut plans).
+int workgroups_per_cu_by_registers(const Plan& p) {
+    if (p.block_threads == kWideBlock) return 2;
+    if (p.balanced) return p.val_type == MI355_VAL_F64 ? 4 : 3;
+    return (p.val_type == MI355_VAL_F64 || p.lanes_per_row >= 16) ? 4 : 3;
 }
 
 int long_steps_for(const Plan& p) {
@@ -535,8 +545,8 @@ int pick_window_elems(Plan& p, int64_t rows_per_workgroup) {
 // or 2 of 512 threads (up to 64 KB each, ~1 KB of it static).
 static int window_budget(const Plan& p, int block_threads, int64_t rows) {
     if (block_threads == kBlock) return kWindowBytes;
-    const size_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
-    const int64_t avail = 63 * 1024 - int64_t(chunk_lds_bytes(0, int(rows), off_bytes, val_bytes));   // <= 64 KB per launch
+    const size_t val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
+    const int64_t avail = 63 * 1024 - int64_t(chunk_lds_bytes(0, int(rows), val_bytes));   // <= 64 KB per launch
     return int(avail < 0 ? 0 : avail);
 }
 
@@ -547,10 +557,12 @@ static int window_budget(const Plan& p, int block_threads, int64_t rows) {
 // S32-band target (LIGHT: 199 -> 195 us once its kernel is held to 128 VGPRs; at 151 only one such workgroup
 // fits a CU and it lost, 237 us).
 void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
+    if (p.val_type == MI355_VAL_F32 && p.lanes_per_row >= 16 && R > 2) R = 2;   // (the kernels' rule: launch_*_window, wide_r)
     auto shape = [&](int block_threads, int64_t nnz_per_chunk) {
         p.block_threads = block_threads;
         const int64_t pass = int64_t(block_threads / p.lanes_per_row) * R;
-        int64_t rows = pick_rows_per_chunk(p.nnz, p.n_rows, p.lanes_per_row, R, block_threads, nnz_per_chunk);
+        int64_t rows = pick_rows_per_chunk(p.nnz, p.n_rows, p.lanes_per_row, R, block_threads, nnz_per_chunk,
+                                           workgroups_per_cu_by_registers(p));
         if (div > 1) rows = (rows / div + pass - 1) / pass * pass;
         if (p.knob.rows_per_chunk > 0) {
             int64_t r = p.knob.rows_per_chunk;
@@ -573,10 +585,10 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
         // of the kernel (2^20 rows: 1 024 chunks on 768 slots).  Shrink the chunk so that the count is a multiple
         // of the slots the plan's LDS and registers leave on the chip.
         if (p.knob.rows_per_chunk <= 0 && p.n_seg < 2) {
-            const size_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
-            const size_t lds = chunk_lds_bytes(p.window_elems, int(p.rows_per_chunk), off_bytes, val_bytes) + 1024;
+            const size_t val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
+            const size_t lds = chunk_lds_bytes(p.window_elems, int(p.rows_per_chunk), val_bytes) + 1024;
             int64_t per_cu = int64_t(160 * 1024 / lds);
-            const int64_t reg_bound = block_threads == kWideBlock ? 2 : 4;
+            const int64_t reg_bound = workgroups_per_cu_by_registers(p);
             if (per_cu > reg_bound) per_cu = reg_bound;
             const int64_t slots = int64_t(kCus) * (per_cu > 0 ? per_cu : 1);
             const int64_t n_chunks = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
@@ -593,14 +605,15 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
         }
     };
     const bool force = p.knob.block > 0;
-    if (force ? p.knob.block == kWideBlock : allow_wide) {
+    if (allow_wide && (!force || p.knob.block == kWideBlock)) {   // (the knob cannot force a workgroup size the kind has no kernel for)
         shape(kWideBlock, 65536);   // (3 072- and 3 584-row chunks with 79 KB of LDS measured worse: 189-194 vs 180 us)
         const int64_t mean = p.n_rows > 0 ? (p.nnz + p.n_rows - 1) / p.n_rows : 1;
         // keep it when (a) the ">= 4 chunks per CU" rule left the chunk long and (b) one window placed from the
         // band serves it (with 64-bit offsets / fp64 / several bands the 64 KB a launch may take is better spent
         // on three workgroups of 256: C4 stand-in 660 us vs 824 us)
         const bool long_chunk = p.rows_per_chunk * mean >= 49152 || p.rows_per_chunk >= kMaxChunkRows;
-        if (force || (long_chunk && p.window_elems > 0 && p.n_seg < 2 && p.window_from_band)) return;
+        // (a forced 512 is honoured unless the window needs several bands: those kernels exist for 256 threads only)
+        if ((force && p.n_seg < 2) || (long_chunk && p.window_elems > 0 && p.n_seg < 2 && p.window_from_band)) return;
     }
     shape(kBlock, 32768);
     // (several bands with two 512-thread workgroups of 78 KB per CU and 1 664-row chunks: measured 722 vs 700 us on the
@@ -610,7 +623,7 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
     // 512 threads with ~78 KB each still fit a CU.  The chunk is then as long as the band leaves room for.
     if (allow_wide && !force && p.probe_ok && !(p.window_elems > 0 && p.n_seg < 2 && p.window_from_band) &&
         p.knob.window < 0 && p.knob.rows_per_chunk <= 0) {
-        const int64_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
+        const int64_t off_bytes = 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;   // (bounds are chunk-relative int32 in LDS)
         const int64_t band = p.band_hi - p.band_lo + 1;
         const int64_t pass = int64_t(kWideBlock / p.lanes_per_row) * R;
         // val (band + rows + 8) + off (rows + 1) + val rows + rows / 8 <= 78 KB

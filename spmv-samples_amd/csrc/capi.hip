@@ -216,6 +216,7 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
     p.kind = kind; p.off_type = off_type; p.val_type = val_type; p.flags = flags;
     p.n_rows = n_rows; p.n_cols = n_cols; p.nnz = nnz; p.Ap = Ap; p.Aj = Aj;
     p.nnz_begin = blk ? blk->phase : 0;
+    p.nnz_read = nnz;
     p.elems_per_lane = 4;
     p.alpha = 1.0;
     p.beta = 0.0;
@@ -234,6 +235,7 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
             return MI355_SPMV_EINVAL;
         }
         p.is_block = true;
+        if ((blk->nnz_begin_whole & ~int64_t(3)) + nnz < w->nnz) p.nnz_read = (nnz + 3) & ~int64_t(3);   // not the last block
         p.block_row_begin = blk->row_begin;
         p.block_chunk_begin = blk->chunk_begin;
         p.lanes_per_row = w->lanes_per_row;

@@ -60,6 +60,7 @@ struct Knobs {
     int giant = -1;            // MI355_SPMV_GIANT            0 = no giant-row slices
     int64_t giant_row = 0;     // MI355_SPMV_GIANT_ROW        nonzeros beyond which a row is giant (>= 4096)
     int plain = 0;             // MI355_SPMV_PLAIN            1 = the 4-byte-per-lane fallback kernels
+    int64_t rel32_limit = 0;   // MI355_SPMV_REL32_LIMIT      tests: nonzero span beyond which a chunk leaves the 32-bit path
     int light_blocks_per_cu = 0;   // MI355_LIGHT_BLOCKS_PER_CU
     int light_chunk_div = 0;   // MI355_LIGHT_CHUNK_DIV
     int merge_block = 0;       // MI355_MERGE_BLOCK           256 | 512
@@ -75,6 +76,10 @@ struct Plan {
     int kind, off_type, val_type, flags;
     int32_t n_rows, n_cols;
     int64_t nnz;               // END offset of the nonzeros: Ap[n_rows] (= their count unless nnz_begin > 0)
+    int64_t nnz_read;          // elements of Aj / Ax the 16-byte loads may touch: nnz, or nnz rounded up to a multiple
+                               // of 4 in a row-block plan that is not the last block (the view continues into the
+                               // next block, so the tail of its last row is read by whole groups exactly as the
+                               // whole matrix's plan reads it: same summation order)
     int64_t nnz_begin;         // Ap[0]: 0, or 1..3 in a row-block plan whose arrays are a 16-byte-aligned view
                                // of a larger CSR (plan_create_block): elements below it belong to no row
     Knobs knob;                // the knobs this plan was shaped under
@@ -134,6 +139,7 @@ struct Plan {
     int32_t* carry_row;    // [n_super]
     void* carry_val;       // [n_super] of value type
     unsigned long long* counters;  // LIGHT: kXcds shards, one 128-B line each
+    bool light_dequeue_once;       // LIGHT, equal-row chunks: one workgroup and one dequeue per chunk (else by index)
     int n_kernels;
     char main_kernel[64];
 };
@@ -154,6 +160,7 @@ int probe_structure(Plan& p);
 int pick_window_elems(Plan& p, int64_t rows_per_workgroup);
 int64_t segment_rows_fit(const Plan& p);
 void shape_chunks(Plan& p, int rows_in_flight, int64_t chunk_div, bool allow_wide);   // VECTOR / LIGHT: block size, chunk, window
+int workgroups_per_cu_by_registers(const Plan& p);   // VECTOR / LIGHT: what the kernels' launch bounds allow
 int long_steps_for(const Plan& p);   // steps of its vector after which a row is left to the long-row pass
 int decide_balance(Plan& p);       // VECTOR / LIGHT, after shape_*: uniform or nnz-balanced chunks
 int build_chunk_table(Plan& p);    // after the scratch is allocated

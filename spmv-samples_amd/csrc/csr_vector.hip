@@ -23,36 +23,60 @@
 
 namespace mi355 {
 
-// (512 threads: two workgroups per CU need 4 waves per SIMD, i.e. <= 128 VGPRs; the fp32 / 32-bit-offset
-// kernel sits at 127 — the bound keeps a later edit from silently halving the occupancy)
-template <int BLOCK, int T, int R, int NSEG, bool ADAPT, typename off_t, typename val_t>
-__global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock ? 4 : 1)) void csr_vector_window_kernel(
-    int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
+// (Registers: 512-thread workgroups and the R = 2 bodies — fp64, and fp32 rows of 33+ nonzeros — are held to 128
+// VGPRs, i.e. two / four workgroups per CU; the 256-thread fp32 R = 4 body needs ~135 and gets 168: three per CU,
+// which is what its 36 KB window of x allows anyway.  shape_chunks sizes a small matrix's single round of chunks
+// by the same numbers: a kernel that silently needs a few more registers than its plan assumed loses 30-40 %
+// there — cant stand-in: 14.7 -> 19-21 us when its body went from 127 to 139 VGPRs.)  The kernel does not depend on the width
+// of the row offsets: a chunk is walked with 32-bit offsets relative to its own first nonzero (xwindow.hpp).
+template <int BLOCK, int T, int R, int NSEG, bool ADAPT, typename val_t>
+__global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock || R == 2 ? 4 : 3)) void csr_vector_window_kernel(
+    int32_t n_rows, int32_t n_cols, int64_t nnz, const ApView Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, ChunkMap cmap,
     int32_t window_cap, BandHint hint, SegmentPlan segs, val_t alpha, val_t beta) {
     // NSEG: 0 = no window (plain gathers), 1 = one window of x in LDS, kMaxSegments = several bands
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2];
-    ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, cmap.rows_cap);
+    ChunkScratch<val_t> scr(s_dyn, window_cap, cmap.rows_cap);
     scr.alpha = alpha;
     scr.beta = beta;
     scr.long_steps = cmap.long_steps;
     scr.giant_len = cmap.giant_len;
-    const unsigned chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    // Equal-row chunks: each XCD walks a contiguous range (neighbouring windows of x hit that L2).  Weight-cut
+    // chunks (power-law matrices, no window to share): chunk = block index, i.e. consecutive chunks go to
+    // different XCDs — the chunks of the dense head of the matrix and those of its near-empty tail take very
+    // different times at equal weight, and a contiguous eighth per XCD leaves the XCDs unevenly loaded.
+    const unsigned chunk = cmap.table ? blockIdx.x : xcd_contiguous_id(blockIdx.x, gridDim.x);
     int64_t rb, re;
     cmap.range(chunk, n_rows, rb, re);
     if (rb >= re) return;   // (balanced plans: a hub row heavier than a chunk leaves empty chunks behind it)
-    stage_chunk_bounds<off_t, val_t>(scr, rb, re, Ap);
+    bool fits;
+    const int64_t base = stage_chunk_bounds<val_t>(scr, rb, re, Ap, cmap.rel_limit, fits);
+    if (!fits) {            // (uniform) more nonzeros than 32-bit chunk-relative offsets reach
+        chunk_rows_wide<BLOCK, val_t>(rb, re, Ap, Aj, Ax, x, y, alpha, beta, cmap.giant_len);
+        return;
+    }
     __syncthreads();
+    const int32_t* const Aj_c = Aj + base;       // the chunk's view: element 0 = its first 16-byte group
+    const val_t* const Ax_c = Ax + base;
+    const int64_t left = nnz - base;
+    const int32_t nnz_c = int32_t(left < kRel32Limit + 32768 ? left : kRel32Limit + 32768);
     // the window is staged inside chunk_rows, behind the first group's stream loads
     if constexpr (NSEG > 1) {
         auto stage = [&] { return stage_x_segments<val_t>(rb, re, n_cols, x, scr.s_x, window_cap, segs); };
-        chunk_rows_any<BLOCK, T, R, true, ADAPT, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, stage, scr);
+        chunk_rows_any<BLOCK, T, R, true, ADAPT, val_t>(rb, re, nnz_c, Aj_c, Ax_c, x, y, stage, scr);
     } else {
-        auto stage = [&] {
-            return stage_x_window<off_t, val_t>(rb, re, n_cols, Ap, Aj, x, scr.s_x, window_cap, s_red, hint);
+        auto first_last = [&](int64_t r, int& first, int& last) {
+            const int32_t s = scr.s_b[r - rb], e = scr.s_b[r - rb + 1];
+            if (e <= s) return false;
+            first = Aj_c[s];
+            last = Aj_c[e - 1];
+            return true;
         };
-        chunk_rows_any<BLOCK, T, R, NSEG == 1, ADAPT, off_t, val_t>(rb, re, nnz, Ap, Aj, Ax, x, y, stage, scr);
+        auto stage = [&] {
+            return stage_x_window<val_t>(rb, re, n_cols, first_last, x, scr.s_x, window_cap, s_red, hint);
+        };
+        chunk_rows_any<BLOCK, T, R, NSEG == 1, ADAPT, val_t>(rb, re, nnz_c, Aj_c, Ax_c, x, y, stage, scr);
     }
 }
 
@@ -87,8 +111,7 @@ void shape_vector(Plan& p) {
         const int t = p.knob.lanes;
         if (t == 2 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64) p.lanes_per_row = t;
     }
-    // (512-thread workgroups need <= 128 VGPRs: not the fp32 kernels with 64-bit offsets, 180)
-    shape_chunks(p, R, 1, p.off_type == MI355_OFF_I32 || p.val_type == MI355_VAL_F64);   // (analyze.hip)
+    shape_chunks(p, R, 1, true);   // (analyze.hip)
     p.grid_blocks = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
     if (p.grid_blocks < 1) p.grid_blocks = 1;
     p.n_tiles = p.grid_blocks;
@@ -115,43 +138,53 @@ void block_grid_vector(Plan& p) {
 
 #endif  // MI355_TU_F64
 
-template <int BLOCK, typename off_t, typename val_t>
-static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
+template <int BLOCK, typename val_t>
+static int launch_vector_window(const Plan& p, const ApView Ap, const val_t* Ax, const val_t* x, val_t* y,
                                 hipStream_t s) {
+    if constexpr (BLOCK == kWideBlock) {
+        // a 512-thread plan is only ever shaped around a window of x; without one (a forced knob) the 256-thread
+        // kernel walks the same chunks (any workgroup size walks any chunk)
+        if (p.window_elems <= 0) return launch_vector_window<kBlock, val_t>(p, Ap, Ax, x, y, s);
+    }
     constexpr int R = rows_in_flight<val_t>();
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
     const dim3 grid((unsigned)p.grid_blocks), block(BLOCK);
-    const off_t nnz = (off_t)p.nnz;
-    const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(off_t), sizeof(val_t));
-    const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, long_steps_for(p), p.n_giant > 0 ? p.giant_len : int64_t(0)};
+    const int64_t nnz = p.nnz_read;
+    const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(val_t));
+    const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks,
+                        long_steps_for(p), p.n_giant > 0 ? p.giant_len : int64_t(0),
+                        p.knob.rel32_limit > 0 ? p.knob.rel32_limit : kRel32Limit, 0};
     SegmentPlan segs;
     segs.n = p.n_seg;
     for (int i = 0; i < kMaxSegments; ++i) { segs.lo[i] = p.seg_lo[i]; segs.hi[i] = p.seg_hi[i]; }
 #define MI355_VEC_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, cmap, (int32_t)p.window_elems, hint, segs, (val_t)p.alpha, (val_t)p.beta
-#define MI355_VEC_CASE(TT)                                                                                   \
-    case TT:                                                                                                 \
-        if (p.window_elems > 0 && p.n_seg >= 2) {                                                            \
-            if (const int st = allow_dynamic_lds((const void*)csr_vector_window_kernel<BLOCK, TT, R, kMaxSegments, false, off_t, val_t>, lds)) return st; \
-            hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, R, kMaxSegments, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS); \
-        }                                                                                                    \
-        else if (p.window_elems > 0) {                                                                       \
-            if (const int st = allow_dynamic_lds((const void*)csr_vector_window_kernel<BLOCK, TT, R, 1, false, off_t, val_t>, lds)) return st; \
-            hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, R, 1, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
-        }                                                                                                    \
-        else                                                                                                 \
-            hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, R, 0, false, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);  \
+    // rows a vector keeps in flight: fp32 with 16 or more lanes per row (rows of 33+ nonzeros) runs with 2 instead of
+    // 4 - a long row keeps its lanes' loads busy by itself, and the body then needs ~95 VGPRs instead of ~135 (four
+    // 256-thread workgroups per CU instead of three: what a small matrix's single round of chunks is sized for)
+    constexpr auto wide_r = [](int tt) constexpr { return (sizeof(val_t) == 4 && tt >= 16) ? 2 : R; };
+#define MI355_VEC_LAUNCH(TT, NSEG_, ADAPT_)                                                                   \
+    do {                                                                                                      \
+        if (const int st = allow_dynamic_lds((const void*)csr_vector_window_kernel<BLOCK, TT, (wide_r(TT)), NSEG_, ADAPT_, val_t>, lds)) return st; \
+        hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, TT, (wide_r(TT)), NSEG_, ADAPT_, val_t>), grid, block, lds, MI355_VEC_ARGS); \
+    } while (0)
+#define MI355_VEC_CASE(TT)                                                                                    \
+    case TT:                                                                                                  \
+        if (p.window_elems > 0 && p.n_seg >= 2) {                                                             \
+            /* (several bands: shape_chunks keeps those plans on 256 threads) */                              \
+            if constexpr (BLOCK == kBlock) MI355_VEC_LAUNCH(TT, kMaxSegments, false);                         \
+            else { set_error("csr_vector: no 512-thread kernel for a multi-band window"); return MI355_SPMV_EINVAL; } \
+        }                                                                                                     \
+        else if (p.window_elems > 0) MI355_VEC_LAUNCH(TT, 1, false);                                          \
+        else if constexpr (BLOCK == kBlock) MI355_VEC_LAUNCH(TT, 0, false);                                   \
         break;
     if constexpr (BLOCK == kBlock) if (p.balanced) {   // vector width per chunk (chunk_rows_any); the T of the template is not used
-        // (the weight-cut layout holds up to 2 K rows of 64-bit bounds and fp64 results next to the window: past 64 KB)
-        if (p.window_elems > 0) {
-            if (const int st = allow_dynamic_lds((const void*)csr_vector_window_kernel<BLOCK, 2, R, 1, true, off_t, val_t>, lds)) return st;
-            hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, 2, R, 1, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);
-        } else {
-            if (const int st = allow_dynamic_lds((const void*)csr_vector_window_kernel<BLOCK, 2, R, 0, true, off_t, val_t>, lds)) return st;
-            hipLaunchKernelGGL((csr_vector_window_kernel<BLOCK, 2, R, 0, true, off_t, val_t>), grid, block, lds, MI355_VEC_ARGS);
-        }
+        // (the weight-cut layout holds up to 2 K rows of bounds and results next to the window: may pass 64 KB)
+        if (p.window_elems > 0) MI355_VEC_LAUNCH(2, 1, true);
+        else MI355_VEC_LAUNCH(2, 0, true);
         MI355_HIP_TRY(hipGetLastError());
-        return launch_giant_rows<off_t, val_t>(p, Ap, Ax, x, y, s);   // (rows too long for one workgroup, if any)
+        return p.off_type == MI355_OFF_I64
+                   ? launch_giant_rows<int64_t, val_t>(p, static_cast<const int64_t*>(Ap.p), Ax, x, y, s)
+                   : launch_giant_rows<int32_t, val_t>(p, static_cast<const int32_t*>(Ap.p), Ax, x, y, s);   // (rows too long for one workgroup, if any)
     }
     switch (p.lanes_per_row) {
         MI355_VEC_CASE(2)
@@ -165,6 +198,7 @@ static int launch_vector_window(const Plan& p, const off_t* Ap, const val_t* Ax,
             return MI355_SPMV_EINVAL;
     }
 #undef MI355_VEC_CASE
+#undef MI355_VEC_LAUNCH
 #undef MI355_VEC_ARGS
     MI355_HIP_TRY(hipGetLastError());
     return MI355_SPMV_OK;
@@ -205,15 +239,18 @@ int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* 
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
     const bool force_plain = p.knob.plain != 0 && !p.is_block;   // tuning / tests (a block keeps the whole plan's order)
-    if (aligned && p.nnz >= 4 && !force_plain)
-        return p.block_threads == kWideBlock ? launch_vector_window<kWideBlock, off_t, val_t>(p, Ap, Ax, x, y, s)
-                                             : launch_vector_window<kBlock, off_t, val_t>(p, Ap, Ax, x, y, s);
+    if (aligned && p.nnz >= 4 && !force_plain) {
+        const ApView view{Ap, sizeof(off_t) == 8 ? 1 : 0};
+        return p.block_threads == kWideBlock ? launch_vector_window<kWideBlock, val_t>(p, view, Ax, x, y, s)
+                                             : launch_vector_window<kBlock, val_t>(p, view, Ax, x, y, s);
+    }
     return launch_vector_plain<off_t, val_t>(p, Ap, Ax, x, y, s);
 }
 
 // One translation unit per value type (csr_vector_f64.hip includes this file with MI355_TU_F64): the two
 // halves of the instantiations compile side by side.
-#ifndef MI355_TU_F64
+#ifdef MI355_TU_PROBE      // (scripts: one kernel instantiated on its own to read its register use quickly)
+#elif !defined(MI355_TU_F64)
 template int launch_vector<int32_t, float>(const Plan&, const int32_t*, const float*, const float*, float*, hipStream_t);
 template int launch_vector<int64_t, float>(const Plan&, const int64_t*, const float*, const float*, float*, hipStream_t);
 #else

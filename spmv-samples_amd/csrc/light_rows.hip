@@ -59,7 +59,10 @@ __device__ __forceinline__ unsigned long long wave_broadcast_u64(unsigned long l
 // dequeue (a dependent ~2 us round trip) per shard.  A counter only grows during an execute, so "dry" is
 // final; a shard reported busy is visited and drained with ordinary dequeues.
 __device__ __forceinline__ unsigned shards_with_rows(unsigned long long* __restrict__ counters, int64_t n_units) {
-    const int lane = threadIdx.x & (kWave - 1);
+    int lane = threadIdx.x & (kWave - 1);
+    // (opaque to the optimiser: the per-lane address and shard size below are loop invariants that it would
+    // otherwise compute once, keep in VGPRs across the whole chunk body of the persistent loop, and spill)
+    asm volatile("" : "+v"(lane));
     bool has = false;
     if (lane < kXcds) {
         const int64_t size = n_units * (lane + 1) / kXcds - n_units * lane / kXcds;
@@ -83,86 +86,159 @@ __device__ __forceinline__ void light_leave(unsigned long long* __restrict__ cou
     }
 }
 
-// (512 threads: two workgroups per CU need 4 waves per SIMD, i.e. <= 128 VGPRs — the persistent loop's
-// state would otherwise take 151 and leave one workgroup per CU; 256 threads: three workgroups per CU need
-// 3 waves per SIMD, <= 168 VGPRs — the per-chunk-width and 64-bit-offset variants would take 177-220)
-template <int BLOCK, int T, int R, int NSEG, bool ADAPT, typename off_t, typename val_t>
-__global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock ? 4 : 3)) void light_rows_window_kernel(
-    int32_t n_rows, int32_t n_cols, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
-    const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
+// (512 threads: two workgroups per CU need 4 waves per SIMD, i.e. <= 128 VGPRs; 256 threads: three workgroups
+// per CU need 3 waves per SIMD, <= 168 VGPRs.)  Like the CSR-vector kernel this one does not depend on the
+// width of the row offsets: a chunk is walked with 32-bit offsets relative to its first nonzero.
+template <int BLOCK, int T, int R, int NSEG, bool ADAPT, typename val_t>
+__global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock || R == 2 ? 4 : 3)) void light_rows_window_kernel(
+    int32_t n_rows, int32_t n_cols, int64_t nnz, const ApView Ap, const int32_t* __restrict__ Aj_arg,
+    const val_t* __restrict__ Ax_arg, const val_t* __restrict__ x_arg, val_t* __restrict__ y_arg,
     unsigned long long* __restrict__ counters, ChunkMap cmap, int32_t window_cap, BandHint hint,
     SegmentPlan segs, val_t alpha, val_t beta) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2];
     __shared__ unsigned long long s_got;
     __shared__ unsigned s_busy;
-    ChunkScratch<off_t, val_t> scr(s_dyn, window_cap, cmap.rows_cap);
+    ChunkScratch<val_t> scr(s_dyn, window_cap, cmap.rows_cap);
     scr.alpha = alpha;
     scr.beta = beta;
     scr.long_steps = cmap.long_steps;
     scr.giant_len = cmap.giant_len;
     // the body of one chunk (all threads; ends with the results swept to y)
     auto run_chunk = [&](int64_t chunk_begin, int64_t chunk_end) {
-        stage_chunk_bounds<off_t, val_t>(scr, chunk_begin, chunk_end, Ap);
+        // Opaque copies of the operand pointers, once per chunk: without them every per-thread address the chunk
+        // body derives from a kernel argument is a loop invariant of the persistent loop, gets computed once up
+        // front, lives in VGPRs across the whole body and is spilled (the same body in the one-chunk-per-workgroup
+        // CSR-vector kernel needs ~130 VGPRs; here it needed more than 256).
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        zero = __builtin_amdgcn_readfirstlane(zero);     // (a scalar the optimiser cannot see through)
+        const int32_t* Aj = Aj_arg + zero;
+        const val_t* Ax = Ax_arg + zero;
+        const val_t* x = x_arg + zero;
+        val_t* y = y_arg + zero;
+        bool fits;
+        const int64_t base = stage_chunk_bounds<val_t>(scr, chunk_begin, chunk_end, Ap, cmap.rel_limit, fits);
+        if (!fits) {          // (uniform) more nonzeros than 32-bit chunk-relative offsets reach
+            chunk_rows_wide<BLOCK, val_t>(chunk_begin, chunk_end, Ap, Aj, Ax, x, y, alpha, beta, cmap.giant_len);
+            __syncthreads();
+            return;
+        }
         __syncthreads();      // (also orders the read of s_got before the next dequeue writes it)
+        const int32_t* const Aj_c = Aj + base;
+        const val_t* const Ax_c = Ax + base;
+        const int64_t left = nnz - base;
+        const int32_t nnz_c = int32_t(left < kRel32Limit + 32768 ? left : kRel32Limit + 32768);
         // the window is staged inside chunk_rows, behind the first group's stream loads
         if constexpr (NSEG > 1) {
             auto stage = [&] {
                 return stage_x_segments<val_t>(chunk_begin, chunk_end, n_cols, x, scr.s_x, window_cap, segs);
             };
-            chunk_rows_any<BLOCK, T, R, true, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
+            chunk_rows_any<BLOCK, T, R, true, ADAPT, val_t>(chunk_begin, chunk_end, nnz_c, Aj_c, Ax_c, x, y, stage, scr);
         } else {
-            auto stage = [&] {
-                return stage_x_window<off_t, val_t>(chunk_begin, chunk_end, n_cols, Ap, Aj, x, scr.s_x, window_cap,
-                                                    s_red, hint);
+            auto first_last = [&](int64_t r, int& first, int& last) {
+                const int32_t s = scr.s_b[r - chunk_begin], e = scr.s_b[r - chunk_begin + 1];
+                if (e <= s) return false;
+                first = Aj_c[s];
+                last = Aj_c[e - 1];
+                return true;
             };
-            chunk_rows_any<BLOCK, T, R, NSEG == 1, ADAPT, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
+            auto stage = [&] {
+                return stage_x_window<val_t>(chunk_begin, chunk_end, n_cols, first_last, x, scr.s_x, window_cap, s_red, hint);
+            };
+            chunk_rows_any<BLOCK, T, R, NSEG == 1, ADAPT, val_t>(chunk_begin, chunk_end, nnz_c, Aj_c, Ax_c, x, y, stage, scr);
         }
     };
-    // No more chunks than workgroups (small matrices): there is nothing to balance — every workgroup takes the
-    // chunk of its index and the counters are not touched.  (The dequeue costs two dependent atomics and a
-    // shard poll per workgroup: 32 vs 14 us on 2^17 rows.)
-    if (cmap.n_chunks <= int64_t(gridDim.x)) {
-        const int64_t chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
-        int64_t chunk_begin, chunk_end;
-        if (chunk < cmap.n_chunks) {
+    // static_mode — few chunks per workgroup slot (small matrices): there is nothing to balance, every workgroup
+    // takes the chunk of its index and the counters are not touched (the dequeue costs two dependent atomics
+    // and a shard poll per workgroup: 32 vs 14 us on 2^17 rows).
+    const bool static_mode = cmap.n_chunks <= int64_t(gridDim.x) && !cmap.dequeue_once;
+    const int home = blockIdx.x % kXcds;
+    if constexpr (!ADAPT) {
+        // Equal-row chunks (uniform matrices): ONE dequeue per workgroup, as many workgroups as chunks.  The
+        // rows are still handed out by the global counters in arrival order — LightSpMV's scheme — but the loop
+        // that keeps a persistent workgroup alive is the hardware dispatcher's: the body then compiles like the
+        // CSR-vector kernel's (no loop-carried state: 127 instead of 168+ VGPRs, so the 512-thread plan fits
+        // two workgroups per CU), and chunks of equal cost need no stealing.  A workgroup starts on the shard of
+        // its XCD (neighbouring chunks share windows of x in that L2) and tries the other shards if it is dry;
+        // there are exactly as many workgroups as chunks, so everybody finds one.
+        int64_t chunk = -1;
+        if (static_mode) {
+            chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
+            if (chunk >= cmap.n_chunks) chunk = -1;
+        } else {
+            for (int visit = 0; visit < kXcds && chunk < 0; ++visit) {   // (uniform over the workgroup)
+                const int shard = (home + visit) % kXcds;
+                const int64_t shard_begin = cmap.n_chunks * shard / kXcds;          // in chunks
+                const int64_t shard_end = cmap.n_chunks * (shard + 1) / kXcds;
+                if (threadIdx.x == 0) s_got = atomicAdd(&counters[shard * kCounterStride], 1ull);
+                __syncthreads();
+                const int64_t c = shard_begin + int64_t(wave_broadcast_u64(s_got));
+                if (c < shard_end) chunk = c;
+                __syncthreads();          // s_got read by all before the next shard's dequeue overwrites it
+            }
+        }
+        if (chunk >= 0) {
+            int64_t chunk_begin, chunk_end;
             cmap.range(chunk, n_rows, chunk_begin, chunk_end);
             if (chunk_begin < chunk_end) run_chunk(chunk_begin, chunk_end);
         }
+        if (!static_mode) light_leave(counters);
         return;
-    }
-    const int home = blockIdx.x % kXcds;
+    } else {
+    // Weight-cut chunks (power-law matrices): a PERSISTENT grid that keeps dequeuing, own shard first, then the
+    // shards that still hold chunks — chunks of the same weight take different times (2 000 near-empty rows vs
+    // 100 long ones), and stealing across the XCDs' shards is what balances them (R-MAT-24: 2.6 ms against
+    // 3.7 ms for one workgroup per chunk in index order).
+    // ONE loop with ONE call of the chunk body (two call sites made the compiler keep the body as a real
+    // function for the biggest instantiations: captures through scratch memory, a call per chunk).
     unsigned busy = 1u << home;
-    for (int visit = 0; visit < kXcds; ++visit) {
-        const int shard = (home + visit) % kXcds;
-        if (visit == 1) {   // own shard dry: ask the others once, all at the same time
-            if (threadIdx.x < kWave) {
-                const unsigned b = shards_with_rows(counters, cmap.n_chunks);
-                if (threadIdx.x == 0) s_busy = b;
+    int visit = 0;
+    bool took_static = false;
+    for (;;) {
+        int64_t chunk = -1;
+        if (static_mode) {
+            if (took_static) break;
+            took_static = true;
+            chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
+            if (chunk >= cmap.n_chunks) break;
+        } else {
+            while (visit < kXcds) {                              // (everything here is uniform over the workgroup)
+                const int shard = (home + visit) % kXcds;
+                if ((busy >> shard) & 1u) {
+                    const int64_t shard_begin = cmap.n_chunks * shard / kXcds;          // in chunks
+                    const int64_t shard_end = cmap.n_chunks * (shard + 1) / kXcds;
+                    if (threadIdx.x == 0) s_got = atomicAdd(&counters[shard * kCounterStride], 1ull);
+                    __syncthreads();
+                    const int64_t c = shard_begin + int64_t(wave_broadcast_u64(s_got));
+                    if (c < shard_end) { chunk = c; break; }
+                    __syncthreads();      // s_got read by all before the next shard's dequeue overwrites it
+                }
+                ++visit;
+                if (visit == 1) {         // own shard dry: ask the others once, all at the same time
+                    if (threadIdx.x < kWave) {
+                        const unsigned b = shards_with_rows(counters, cmap.n_chunks);
+                        if (threadIdx.x == 0) s_busy = b;
+                    }
+                    __syncthreads();
+                    // (LDS contents are the same for every lane, but the compiler cannot know: a VGPR here would
+                    // make the branches on `busy` divergent)
+                    busy = __builtin_amdgcn_readfirstlane(s_busy);
+                }
             }
-            __syncthreads();
-            busy = s_busy;
+            if (chunk < 0) break;
         }
-        if (!((busy >> shard) & 1u)) continue;      // uniform over the workgroup
-        const int64_t shard_begin = cmap.n_chunks * shard / kXcds;          // in chunks
-        const int64_t shard_end = cmap.n_chunks * (shard + 1) / kXcds;
-        while (true) {
-            if (threadIdx.x == 0) s_got = atomicAdd(&counters[shard * kCounterStride], 1ull);
-            __syncthreads();
-            const int64_t chunk = shard_begin + int64_t(wave_broadcast_u64(s_got));
-            if (chunk >= shard_end) break;  // uniform over the workgroup
-            int64_t chunk_begin, chunk_end;
-            cmap.range(chunk, n_rows, chunk_begin, chunk_end);
-            if (chunk_begin >= chunk_end) {   // a hub row heavier than a chunk leaves empty chunks behind it
-                __syncthreads();              // s_got read by all before the next dequeue overwrites it
-                continue;
-            }
-            run_chunk(chunk_begin, chunk_end);
-            __syncthreads();  // every wave is done with the window before it is refilled
+        int64_t chunk_begin, chunk_end;
+        cmap.range(chunk, n_rows, chunk_begin, chunk_end);
+        if (chunk_begin >= chunk_end) {   // a hub row heavier than a chunk leaves empty chunks behind it
+            __syncthreads();              // s_got read by all before the next dequeue overwrites it
+            continue;
         }
-        __syncthreads();      // s_got read by all before the next shard's dequeue overwrites it
+        run_chunk(chunk_begin, chunk_end);
+        __syncthreads();                  // every wave is done with the window before it is refilled
     }
-    light_leave(counters);
+    if (!static_mode) light_leave(counters);
+    }
 }
 
 // 4-byte-per-lane form for operands that are not 16-byte aligned: one dequeue per wave.
@@ -217,11 +293,11 @@ static int64_t light_resident(const Plan& p, int64_t rows) {
     // and by registers (3 workgroups of 256 threads, 2 of 512).  Asking for more than fits leaves the surplus
     // workgroups to start when the others have finished everything (4 asked / 3 resident: 207 vs 200 us).
     if (p.knob.light_blocks_per_cu > 0) return int64_t(kCus) * p.knob.light_blocks_per_cu;
-    const size_t off_bytes = p.off_type == MI355_OFF_I64 ? 8 : 4, val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
-    const size_t lds = chunk_lds_bytes(p.window_elems, int(rows), off_bytes, val_bytes) + 1024;
+    const size_t val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
+    const size_t lds = chunk_lds_bytes(p.window_elems, int(rows), val_bytes) + 1024;
     int64_t per_cu = int64_t(160 * 1024 / lds);
     // registers: the kernels are bounded to 3 waves per SIMD (256 threads) / 4 (512 threads), see the kernel
-    const int64_t reg_bound = p.block_threads == kWideBlock ? 2 : 3;
+    const int64_t reg_bound = workgroups_per_cu_by_registers(p);
     if (per_cu > reg_bound) per_cu = reg_bound;
     if (per_cu < 1) per_cu = 1;
     return int64_t(kCus) * per_cu;
@@ -231,9 +307,13 @@ static int64_t light_resident(const Plan& p, int64_t rows) {
 // chunks per workgroup to balance; one workgroup per chunk, taken by index, when there are at most two per slot
 // (the dequeue — two dependent atomics and a poll per workgroup — then costs more than it can balance away).
 static int64_t light_grid(const Plan& p, int64_t n_chunks, int64_t resident) {
-    (void)p;
-    int64_t blocks = n_chunks <= 2 * resident ? n_chunks : resident;
+    // equal-row chunks: one workgroup (and one dequeue) per chunk; weight-cut chunks: the persistent grid
+    int64_t blocks = (!p.balanced || n_chunks <= 2 * resident) ? n_chunks : resident;
     return blocks < 1 ? 1 : blocks;
+}
+// equal-row chunks: take the chunk by index (no counter) when there are at most two per workgroup slot
+static bool light_dequeue_once(const Plan& p, int64_t n_chunks, int64_t resident) {
+    return !p.balanced && n_chunks > 2 * resident;
 }
 
 void shape_light(Plan& p) {
@@ -242,10 +322,10 @@ void shape_light(Plan& p) {
     const int div = p.knob.light_chunk_div;
     // chunks: the static kind's size (halving them cost 6 % on the S32-band target: the
     // window of x is staged per chunk), never below one pass of the workgroup
-    // (512-thread workgroups only with 32-bit offsets: under the 128-VGPR cap the 64-bit kernels spill 80 registers)
-    shape_chunks(p, R, div > 0 ? div : 1, p.off_type == MI355_OFF_I32);
+    shape_chunks(p, R, div > 0 ? div : 1, true);
     p.n_tiles = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
     p.grid_blocks = light_grid(p, p.n_tiles, light_resident(p, p.rows_per_chunk));
+    p.light_dequeue_once = light_dequeue_once(p, p.n_tiles, light_resident(p, p.rows_per_chunk));
     p.n_kernels = 1;
     snprintf(p.main_kernel, sizeof(p.main_kernel), "light_rows_window_kernel");
 }
@@ -259,53 +339,65 @@ void reshape_light_balanced(Plan& p) {
     p.window_elems = pick_window_elems(p, p.rows_cap);
     if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }
     p.grid_blocks = light_grid(p, p.n_chunks, light_resident(p, p.rows_cap));
+    p.light_dequeue_once = false;
 }
 
 void block_grid_light(Plan& p) {
     p.n_tiles = p.n_chunks;
     p.grid_blocks = light_grid(p, p.n_chunks, light_resident(p, p.balanced ? p.rows_cap : p.rows_per_chunk));
+    p.light_dequeue_once = light_dequeue_once(p, p.n_chunks, light_resident(p, p.balanced ? p.rows_cap : p.rows_per_chunk));
     snprintf(p.main_kernel, sizeof(p.main_kernel), "light_rows_window_kernel");
 }
 
 #endif  // MI355_TU_F64
 
-template <int BLOCK, typename off_t, typename val_t>
-static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
+template <int BLOCK, typename val_t>
+static int launch_light_window(const Plan& p, const ApView Ap, const val_t* Ax, const val_t* x, val_t* y,
                                hipStream_t s) {
+    if constexpr (BLOCK == kWideBlock) {
+        // (see launch_vector_window: no 512-thread kernel without a window of x)
+        if (p.window_elems <= 0) return launch_light_window<kBlock, val_t>(p, Ap, Ax, x, y, s);
+    }
     constexpr int R = light_rows_in_flight<val_t>();
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
     const dim3 grid((unsigned)p.grid_blocks), block(BLOCK);
-    const off_t nnz = (off_t)p.nnz;
-    const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, long_steps_for(p), p.n_giant > 0 ? p.giant_len : int64_t(0)};
-    const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(off_t), sizeof(val_t));
+    const int64_t nnz = p.nnz_read;
+    const ChunkMap cmap{p.balanced ? p.chunk_row : nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks,
+                        long_steps_for(p), p.n_giant > 0 ? p.giant_len : int64_t(0),
+                        p.knob.rel32_limit > 0 ? p.knob.rel32_limit : kRel32Limit,
+                        p.light_dequeue_once ? 1 : 0};
+    const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(val_t));
     SegmentPlan segs;
     segs.n = p.n_seg;
     for (int i = 0; i < kMaxSegments; ++i) { segs.lo[i] = p.seg_lo[i]; segs.hi[i] = p.seg_hi[i]; }
 #define MI355_LIGHT_ARGS s, p.n_rows, p.n_cols, nnz, Ap, p.Aj, Ax, x, y, p.counters, cmap, (int32_t)p.window_elems, hint, segs, (val_t)p.alpha, (val_t)p.beta
+    // rows a vector keeps in flight: fp32 with 16 or more lanes per row (rows of 33+ nonzeros) runs with 2 instead of
+    // 4 - a long row keeps its lanes' loads busy by itself, and the body then needs ~95 VGPRs instead of ~135 (four
+    // 256-thread workgroups per CU instead of three: what a small matrix's single round of chunks is sized for)
+    constexpr auto wide_r = [](int tt) constexpr { return (sizeof(val_t) == 4 && tt >= 16) ? 2 : R; };
+#define MI355_LIGHT_LAUNCH(TT, NSEG_, ADAPT_)                                                                  \
+    do {                                                                                                       \
+        if (const int st = allow_dynamic_lds((const void*)light_rows_window_kernel<BLOCK, TT, (wide_r(TT)), NSEG_, ADAPT_, val_t>, lds)) return st; \
+        hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, TT, (wide_r(TT)), NSEG_, ADAPT_, val_t>), grid, block, lds, MI355_LIGHT_ARGS); \
+    } while (0)
 #define MI355_LIGHT_CASE(TT)                                                                                   \
     case TT:                                                                                                   \
         if (p.window_elems > 0 && p.n_seg >= 2) {                                                              \
-            if (const int st = allow_dynamic_lds((const void*)light_rows_window_kernel<BLOCK, TT, R, kMaxSegments, false, off_t, val_t>, lds)) return st; \
-            hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, TT, R, kMaxSegments, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS); \
+            /* (several bands: shape_chunks keeps those plans on 256 threads) */                               \
+            if constexpr (BLOCK == kBlock) MI355_LIGHT_LAUNCH(TT, kMaxSegments, false);                        \
+            else { set_error("light_rows: no 512-thread kernel for a multi-band window"); return MI355_SPMV_EINVAL; } \
         }                                                                                                      \
-        else if (p.window_elems > 0) {                                                                         \
-            if (const int st = allow_dynamic_lds((const void*)light_rows_window_kernel<BLOCK, TT, R, 1, false, off_t, val_t>, lds)) return st; \
-            hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, TT, R, 1, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
-        }                                                                                                      \
-        else                                                                                                   \
-            hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, TT, R, 0, false, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);  \
+        else if (p.window_elems > 0) MI355_LIGHT_LAUNCH(TT, 1, false);                                         \
+        else if constexpr (BLOCK == kBlock) MI355_LIGHT_LAUNCH(TT, 0, false);                                  \
         break;
     if constexpr (BLOCK == kBlock) if (p.balanced) {   // vector width per chunk (chunk_rows_any); the T of the template is not used
-        // (the weight-cut layout holds up to 2 K rows of 64-bit bounds and fp64 results next to the window: past 64 KB)
-        if (p.window_elems > 0) {
-            if (const int st = allow_dynamic_lds((const void*)light_rows_window_kernel<BLOCK, 2, R, 1, true, off_t, val_t>, lds)) return st;
-            hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, 2, R, 1, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);
-        } else {
-            if (const int st = allow_dynamic_lds((const void*)light_rows_window_kernel<BLOCK, 2, R, 0, true, off_t, val_t>, lds)) return st;
-            hipLaunchKernelGGL((light_rows_window_kernel<BLOCK, 2, R, 0, true, off_t, val_t>), grid, block, lds, MI355_LIGHT_ARGS);
-        }
+        // (the weight-cut layout holds up to 2 K rows of bounds and results next to the window: may pass 64 KB)
+        if (p.window_elems > 0) MI355_LIGHT_LAUNCH(2, 1, true);
+        else MI355_LIGHT_LAUNCH(2, 0, true);
         MI355_HIP_TRY(hipGetLastError());
-        return launch_giant_rows<off_t, val_t>(p, Ap, Ax, x, y, s);   // (rows too long for one workgroup, if any)
+        return p.off_type == MI355_OFF_I64
+                   ? launch_giant_rows<int64_t, val_t>(p, static_cast<const int64_t*>(Ap.p), Ax, x, y, s)
+                   : launch_giant_rows<int32_t, val_t>(p, static_cast<const int32_t*>(Ap.p), Ax, x, y, s);   // (rows too long for one workgroup, if any)
     }
     switch (p.lanes_per_row) {
         MI355_LIGHT_CASE(2)
@@ -319,6 +411,7 @@ static int launch_light_window(const Plan& p, const off_t* Ap, const val_t* Ax, 
             return MI355_SPMV_EINVAL;
     }
 #undef MI355_LIGHT_CASE
+#undef MI355_LIGHT_LAUNCH
     MI355_HIP_TRY(hipGetLastError());
     return MI355_SPMV_OK;
 }
@@ -355,14 +448,17 @@ int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x
     if (p.n_rows == 0) return MI355_SPMV_OK;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
-    if (aligned && p.nnz >= 4)
-        return p.block_threads == kWideBlock ? launch_light_window<kWideBlock, off_t, val_t>(p, Ap, Ax, x, y, s)
-                                             : launch_light_window<kBlock, off_t, val_t>(p, Ap, Ax, x, y, s);
+    if (aligned && p.nnz >= 4) {
+        const ApView view{Ap, sizeof(off_t) == 8 ? 1 : 0};
+        return p.block_threads == kWideBlock ? launch_light_window<kWideBlock, val_t>(p, view, Ax, x, y, s)
+                                             : launch_light_window<kBlock, val_t>(p, view, Ax, x, y, s);
+    }
     return launch_light_plain<off_t, val_t>(p, Ap, Ax, x, y, s);
 }
 
 // One translation unit per value type (light_rows_f64.hip includes this file with MI355_TU_F64).
-#ifndef MI355_TU_F64
+#ifdef MI355_TU_PROBE      // (scripts: one kernel instantiated on its own to read its register use quickly)
+#elif !defined(MI355_TU_F64)
 template int launch_light<int32_t, float>(const Plan&, const int32_t*, const float*, const float*, float*, hipStream_t);
 template int launch_light<int64_t, float>(const Plan&, const int64_t*, const float*, const float*, float*, hipStream_t);
 #else

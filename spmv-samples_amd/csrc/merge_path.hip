@@ -145,7 +145,6 @@ __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
     __shared__ int s_re[BLOCK * IPT + 1];                               // tile-relative row ends
     __shared__ val_t s_wave_sum[BLOCK / kWave];
     __shared__ int s_wave_flag[BLOCK / kWave];
-    __shared__ val_t s_carry;
     __shared__ int s_red[2];
 
     const unsigned sup = xcd_contiguous_id(blockIdx.x, gridDim.x);
@@ -180,8 +179,15 @@ __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
     if constexpr (VEC) issue(y0);
     // the window of x for all rows this run touches (incl. the row left open at its end), staged while the
     // first tile's stream is in flight
+    auto first_last = [&](int64_t r, int& fc, int& lc) {
+        const off_t s = Ap[r], e = Ap[r + 1];
+        if (e <= s) return false;
+        fc = Aj[s];
+        lc = Aj[e - 1];
+        return true;
+    };
     const XWindow<val_t> win =
-        stage_x_window<off_t, val_t>(row_lo, row_hi, n_cols, Ap, Aj, x, s_x, window_cap, s_red, hint);
+        stage_x_window<val_t>(row_lo, row_hi, n_cols, first_last, x, s_x, window_cap, s_red, hint);
     // the first BLOCK row ends of a tile are fetched one tile ahead as well (a tile with more
     // rows than that — mean row length below 8 — loads the rest when it gets there)
     auto fetch_row_end = [&](int xa, int xe) -> int64_t {
@@ -361,14 +367,22 @@ __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
         }
         __syncthreads();
         val_t prefix = block_carry;  // block-inclusive value at the end of the previous wave
-        for (int w = 0; w < wave; ++w) prefix = s_wave_flag[w] ? s_wave_sum[w] : SR::reduce(prefix, s_wave_sum[w]);
+        val_t total = block_carry;   // ... and at the end of the last wave: the row still open at the end of the tile
+#pragma unroll
+        for (int w = 0; w < BLOCK / kWave; ++w) {
+            const val_t ws = s_wave_sum[w];
+            total = s_wave_flag[w] ? ws : SR::reduce(total, ws);
+            if (w + 1 == wave) prefix = total;
+        }
         const val_t incl = sf ? sv : SR::reduce(prefix, sv);
         val_t carry_in = __shfl_up(incl, 1, kWave);
         if (lane64 == 0) carry_in = prefix;
         if (first_end >= 0) put(int64_t(x0) + first_end, SR::reduce(carry_in, first_val));
-        if (tid == BLOCK - 1) s_carry = incl;   // the row still open at the end of the tile
-        __syncthreads();                          // also frees s_nz / s_re / s_wave_* for the next tile
-        block_carry = s_carry;
+        // No third barrier (round 1 passed the tile's carry through one more LDS word): every thread folds the
+        // wave totals itself, and the next tile cannot disturb this one — it writes s_nz / s_re before ITS first
+        // barrier and the wave totals after it, and no wave gets there before every wave has left the second
+        // barrier of this tile with its reads of s_nz / s_re done (they precede that barrier).
+        block_carry = total;
         x0 = x1; y0 = y1;
         x1 = x2; y1 = y2;
     }

@@ -107,14 +107,18 @@ struct BandHint {
     bool use;
 };
 
-template <typename off_t, typename val_t>
+// first_last(r, first, last): the first and last stored column of row r (false when the row is empty) — the
+// merge kernel reads them through Ap, the row-chunk kernels through the bounds they already hold in LDS.
+template <typename val_t, typename FirstLast>
 __device__ __forceinline__ XWindow<val_t> stage_x_window(int64_t rb, int64_t re, int32_t n_cols,
-                                                         const off_t* __restrict__ Ap,
-                                                         const int32_t* __restrict__ Aj,
+                                                         FirstLast&& first_last,
                                                          const val_t* __restrict__ x, val_t* s_x,
                                                          int32_t cap, int* s_red,
                                                          const BandHint hint = BandHint{0, 0, false}) {
-    const int tid = threadIdx.x;
+    // (opaque copy of the thread index: inside a persistent loop the optimiser otherwise hoists this function's
+    // per-thread addresses out of the loop, keeps them in VGPRs across the whole chunk body and spills them)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     int lo = INT32_MAX, hi = -1;
     if (cap <= 0) {        // the plan decided against a window: no sampling
         XWindow<val_t> none;
@@ -135,9 +139,8 @@ __device__ __forceinline__ XWindow<val_t> stage_x_window(int64_t rb, int64_t re,
     // (measured: -25 % on the S32-band target).
     if (tid < kSamples && re > rb) {
         const int64_t r = rb + ((re - 1 - rb) * tid) / (kSamples - 1);
-        const off_t s = Ap[r], e = Ap[r + 1];
-        if (e > s) {
-            const int first = Aj[s], last = Aj[e - 1];
+        int first, last;
+        if (first_last(r, first, last)) {
             lo = min(first, last);
             hi = max(first, last);
         }
@@ -202,7 +205,8 @@ __device__ __forceinline__ XWindowN<val_t> stage_x_segments(int64_t rb, int64_t 
                                                             int32_t cap, const SegmentPlan& plan) {
     constexpr int PER16 = 16 / int(sizeof(val_t));
     using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));        // (see stage_x_window)
     XWindowN<val_t> win;
     win.s_x = s_x;
     int off = 0;
@@ -247,10 +251,31 @@ __device__ __forceinline__ val_t window_gather(const XWindow<val_t>& win, const 
 }
 
 // LDS scratch of one workgroup for chunk_rows, carved from dynamic LDS behind the window:
-//   [ window_elems values of x ][ rows+1 row bounds (off_t) ][ rows results (val_t) ][ rows/32 flag words ]
+//   [ window_elems values of x ][ rows+1 row bounds (int32, chunk-relative) ][ rows results (val_t) ][ rows/32 flag words ]
 constexpr int kMaxChunkRows = 2048;   // upper bound of rows per chunk (pick_rows_per_chunk)
 constexpr int kLongSteps = 16;        // a row is "long" beyond this many steps of its T-lane vector
 constexpr int kHugeRow = 1024;        // a long row beyond this many nonzeros is summed by the whole workgroup
+// A chunk is walked with 32-bit offsets relative to its first 16-byte group whatever the width of Ap (the
+// merge kernel does the same with its tiles): half the LDS for the bounds, no 64-bit arithmetic or register
+// pairs in the loop, and ONE kernel body for both offset widths.  A chunk whose nonzeros span more than this
+// (rows of ~10^9 nonzeros that the giant-row pass did not take) goes through chunk_rows_wide instead.
+constexpr int64_t kRel32Limit = int64_t(INT32_MAX) - 65536;
+
+// A 64-bit value that is the same in every lane, moved to scalar registers.
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(unsigned(uint64_t(v) >> 32));
+    return int64_t((uint64_t(hi) << 32) | lo);
+}
+
+// Row offsets of either width behind one kernel signature (a uniform branch per load, in prologues only).
+struct ApView {
+    const void* p;
+    int wide;       // 1 = int64 offsets, 0 = int32
+    __device__ __forceinline__ int64_t at(int64_t i) const {
+        return wide ? static_cast<const int64_t*>(p)[i] : int64_t(static_cast<const int32_t*>(p)[i]);
+    }
+};
 
 // How chunk ids map to rows.  Uniform plans: chunk c = rows [c * rows_per_chunk, ...).  nnz-balanced plans
 // (analyze.hip, decide_balance): boundaries from a table built at plan creation, so that a chunk of a
@@ -262,6 +287,8 @@ struct ChunkMap {
     int64_t n_chunks;
     int32_t long_steps;       // a row is "long" (left to the second pass) beyond this many steps of its vector
     int64_t giant_len;        // > 0: a row beyond this many nonzeros is left to the giant-row kernels (giant_rows.hpp)
+    int64_t rel_limit;        // nonzero span a chunk may have on the 32-bit path (kRel32Limit; smaller in tests)
+    int32_t dequeue_once;     // LIGHT, equal-row chunks: 1 = every workgroup takes its chunk from the counters, 0 = by index
     __device__ __forceinline__ void range(int64_t c, int32_t n_rows, int64_t& rb, int64_t& re) const {
         if (table) {
             rb = table[c];
@@ -274,15 +301,15 @@ struct ChunkMap {
 };
 
 __host__ __device__ inline size_t lds_align16(size_t v) { return (v + 15) & ~size_t(15); }
-__host__ __device__ inline size_t chunk_lds_bytes(int window_elems, int rows, size_t off_bytes, size_t val_bytes) {
-    return lds_align16(size_t(window_elems) * val_bytes) + lds_align16(size_t(rows + 1) * off_bytes) +
+__host__ __device__ inline size_t chunk_lds_bytes(int window_elems, int rows, size_t val_bytes) {
+    return lds_align16(size_t(window_elems) * val_bytes) + lds_align16(size_t(rows + 1) * 4) +
            lds_align16(size_t(rows) * val_bytes) + lds_align16(size_t(rows / 32 + 1) * 4);
 }
 
-template <typename off_t, typename val_t>
+template <typename val_t>
 struct ChunkScratch {
     val_t* s_x;           // window_elems
-    off_t* s_b;           // rows + 1 : Ap[chunk_begin .. chunk_end]
+    int32_t* s_b;         // rows + 1 : Ap[chunk_begin .. chunk_end] - base
     val_t* s_y;           // rows     : results of the chunk, stored to y in one coalesced sweep
     unsigned* long_map;   // rows / 32 + 1 : one bit per row, set = long row, summed in the second pass
     val_t alpha, beta;    // y = alpha * (A x) + beta * y   (1, 0 unless mi355_spmv_plan_set_alpha_beta)
@@ -291,8 +318,8 @@ struct ChunkScratch {
     __device__ ChunkScratch(unsigned char* base, int window_elems, int rows) {
         s_x = reinterpret_cast<val_t*>(base);
         base += lds_align16(size_t(window_elems) * sizeof(val_t));
-        s_b = reinterpret_cast<off_t*>(base);
-        base += lds_align16(size_t(rows + 1) * sizeof(off_t));
+        s_b = reinterpret_cast<int32_t*>(base);
+        base += lds_align16(size_t(rows + 1) * 4);
         s_y = reinterpret_cast<val_t*>(base);
         base += lds_align16(size_t(rows) * sizeof(val_t));
         long_map = reinterpret_cast<unsigned*>(base);
@@ -301,19 +328,29 @@ struct ChunkScratch {
     }
 };
 
-// Before the barrier that precedes chunk_rows (stage_x_window's): copy the chunk's row
-// bounds into LDS and clear the long-row flags.
-template <typename off_t, typename val_t>
-__device__ __forceinline__ void stage_chunk_bounds(const ChunkScratch<off_t, val_t>& scr, int64_t chunk_begin,
-                                                   int64_t chunk_end, const off_t* __restrict__ Ap) {
+// Before the barrier that precedes chunk_rows: copy the chunk's row bounds into LDS, relative to
+// base = Ap[chunk_begin] & ~3 (returned: the chunk's Aj / Ax start there, 16-byte aligned), and clear the
+// long-row flags.  fits = the chunk's nonzeros span less than `limit` (uniform over the workgroup).
+template <typename val_t>
+__device__ __forceinline__ int64_t stage_chunk_bounds(const ChunkScratch<val_t>& scr, int64_t chunk_begin,
+                                                      int64_t chunk_end, const ApView Ap, int64_t limit, bool& fits) {
     const int rows = int(chunk_end - chunk_begin);
-    for (int i = threadIdx.x; i <= rows; i += int(blockDim.x)) scr.s_b[i] = Ap[chunk_begin + i];
-    for (int i = threadIdx.x; i < rows / 32 + 1; i += int(blockDim.x)) scr.long_map[i] = 0u;
+    // (every lane loads the same two words; the copies through readfirstlane tell the compiler so: base then
+    // lives in an SGPR pair and the chunk's Aj / Ax views are scalar bases with 32-bit lane offsets, instead of
+    // 64-bit address arithmetic in VGPR pairs all through the loop)
+    const int64_t base = uniform_i64(Ap.at(chunk_begin)) & ~int64_t(3);
+    fits = uniform_i64(Ap.at(chunk_end)) - base <= limit;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // (opaque: per-thread LDS addresses stay inside, see stage_x_window)
+    if (fits)
+        for (int i = tid; i <= rows; i += int(blockDim.x)) scr.s_b[i] = int32_t(Ap.at(chunk_begin + i) - base);
+    for (int i = tid; i < rows / 32 + 1; i += int(blockDim.x)) scr.long_map[i] = 0u;
+    return base;
 }
 
 // One step of 4 nonzeros of one lane: Aj/Ax group at j (16-byte aligned element index).
-template <typename off_t, typename val_t>
-__device__ __forceinline__ void load_group(off_t j, off_t nnz, const int32_t* __restrict__ Aj,
+template <typename val_t>
+__device__ __forceinline__ void load_group(int32_t j, int32_t nnz, const int32_t* __restrict__ Aj,
                                            const val_t* __restrict__ Ax, int4v& c,
                                            typename Vec4<val_t>::type& a) {
     using v4 = typename Vec4<val_t>::type;
@@ -331,8 +368,8 @@ __device__ __forceinline__ void load_group(off_t j, off_t nnz, const int32_t* __
 }
 
 // Rows [chunk_begin, chunk_end) by this workgroup: T lanes per row, R rows per vector per
-// group, 4 nonzeros per lane per step.  Structure (each point is a measured win on the
-// S32-band target, tools/exp_pipe.hip):
+// group, 4 nonzeros per lane per step.  Aj / Ax / nnz are CHUNK-RELATIVE (see stage_chunk_bounds).
+// Structure (each point is a measured win on the S32-band target, tools/exp_pipe.hip):
 //  * row bounds come from LDS (stage_chunk_bounds), so the only vector-memory traffic in
 //    the loop is the Aj/Ax stream itself;
 //  * the loop is software-pipelined by hand: the stream loads of group g+1 are issued
@@ -354,38 +391,56 @@ __device__ __forceinline__ void load_group(off_t j, off_t nnz, const int32_t* __
 //    are in flight), so a chunk's prologue costs one memory round trip, not two.
 // All BLOCK threads of the workgroup must call (wave-wide shuffles and barriers inside); the caller
 // has run stage_chunk_bounds + a barrier; `stage()` returns the window and ends with a barrier.
-template <int BLOCK, int T, int R, bool WINDOW, typename off_t, typename val_t, typename StageFn>
-__device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_end, off_t nnz,
-                                           const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
+template <int BLOCK, int T, int R, bool WINDOW, typename val_t, typename StageFn>
+__device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_end, int32_t nnz,
+                                           const int32_t* __restrict__ Aj,
                                            const val_t* __restrict__ Ax, const val_t* __restrict__ x,
                                            val_t* __restrict__ y, StageFn&& stage,
-                                           const ChunkScratch<off_t, val_t>& scr) {
+                                           const ChunkScratch<val_t>& scr) {
     using v4 = typename Vec4<val_t>::type;
+    using off_t = int32_t;                                 // chunk-relative offsets
     constexpr int VECS = BLOCK / T;
     constexpr int WAVES = BLOCK / kWave;
     constexpr int STRIDE = VECS * R;                       // rows per group
     const off_t LONG = off_t(T) * 4 * scr.long_steps;
     const int lane = threadIdx.x & (T - 1);
-    const int vec = threadIdx.x / T;
     const int rows = int(chunk_end - chunk_begin);
     const int n_groups = (rows + STRIDE - 1) / STRIDE;
     const off_t nnz_vec = nnz & ~off_t(3);                 // 16-byte loads stay below this element
     const off_t j_max = nnz_vec - 4;                       // callers guarantee nnz >= 4 (launch_*: plain kernel otherwise)
 
+    // Which rows a vector owns.  A wave holds VW = 64 / T vectors; in one group it covers VW * R consecutive
+    // rows, and slot r of vector v is row r * VW + v of them — so ONE load instruction (slot r of every vector)
+    // reads VW CONSECUTIVE rows, a contiguous piece of Aj / Ax.  (Round 1 gave a vector R adjacent rows: an
+    // instruction then read every R-th row; harmless while rows are whole cache lines (32 nonzeros), but with
+    // 27 or 28 per row every line is shared by two rows, i.e. fetched by two different instructions: a single
+    // fp64 band fell from 6.6 TB/s at 32 per row to 4.4 at 27.)
+    constexpr int VW = kWave / T;
+    const int row_in_wave = (threadIdx.x & (kWave - 1)) / T;
+    const int wave_rows0 = (threadIdx.x / kWave) * (VW * R);
+#ifdef MI355_ROW_MAP_ADJACENT   // (A/B builds only: round 1's mapping, a vector owns R adjacent rows)
+    auto row_of = [&](int g, int r) { return g * STRIDE + int(threadIdx.x / T) * R + r; };
+#else
+    auto row_of = [&](int g, int r) { return g * STRIDE + wave_rows0 + r * VW + row_in_wave; };
+#endif
     struct Group {
-        off_t b[R + 1];   // bounds of the vector's R rows
-        off_t j[R];       // first element of this lane's step-0 group
+        off_t lo[R], hi[R];   // bounds of the vector's R rows
+        off_t j[R];           // first element of this lane's step-0 group
         int4v c[R];
         v4 a[R];
     };
     // issue the step-0 loads of group g (g may be past the end: rows clamp to empty)
     auto issue = [&](int g, Group& G) {
 #pragma unroll
-        for (int r = 0; r <= R; ++r) G.b[r] = scr.s_b[min(g * STRIDE + vec * R + r, rows)];
+        for (int r = 0; r < R; ++r) {
+            const int row = row_of(g, r);
+            G.lo[r] = scr.s_b[min(row, rows)];
+            G.hi[r] = scr.s_b[min(row + 1, rows)];
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            G.j[r] = (G.b[r] & ~off_t(3)) + off_t(lane) * 4;
-            off_t jl = G.j[r] < G.b[r + 1] ? G.j[r] : (G.b[r] & ~off_t(3));
+            G.j[r] = (G.lo[r] & ~off_t(3)) + off_t(lane) * 4;
+            off_t jl = G.j[r] < G.hi[r] ? G.j[r] : (G.lo[r] & ~off_t(3));
             jl = jl < j_max ? jl : j_max;
             // straight-line, branch-free: hipcc serialises (vmcnt(0)) around loads in branches
             G.c[r] = stream_load(reinterpret_cast<const int4v*>(Aj + jl));
@@ -401,8 +456,6 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     // outside it is fetched and consumed under ONE branch per 4 elements, so the common path
     // never waits on vector memory.  !WINDOW: plain gathers (masked elements hold a legal
     // column of a neighbouring row, or 0, so the address is always in range).
-    // (the valid elements are e in [e_lo, e_hi): the callers turn the row bounds into these two small ints once
-    // per 4 elements, so the per-element test is 32-bit whatever off_t is)
     auto accumulate = [&](val_t& sum, const int4v& c, const v4& a, off_t j, off_t lo, off_t hi) {
         const off_t d_lo = lo - j, d_hi = hi - j;
         const int e_lo = d_lo > 0 ? int(d_lo) : 0;                 // lo - j <= 3 wherever this is called
@@ -435,7 +488,6 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
         }
     };
     auto consume = [&](int g, const Group& G) {
-        const int local0 = g * STRIDE + vec * R;
         val_t sum[R];
         off_t jn[R], hi[R];
         bool deferred[R];
@@ -444,12 +496,12 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
         for (int r = 0; r < R; ++r) {
             // (uniform over the T lanes of the vector; a giant row always takes the long-row path, where it is
             // zeroed for the slice kernels, whatever the long-steps knob says)
-            const off_t len_r = G.b[r + 1] - G.b[r];
+            const off_t len_r = G.hi[r] - G.lo[r];
             deferred[r] = len_r > LONG || (scr.giant_len > 0 && int64_t(len_r) > scr.giant_len);
             // the 16-byte path covers elements below nnz_vec; a long row is left to pass 2
-            hi[r] = deferred[r] ? G.b[r] : (G.b[r + 1] < nnz_vec ? G.b[r + 1] : nnz_vec);
+            hi[r] = deferred[r] ? G.lo[r] : (G.hi[r] < nnz_vec ? G.hi[r] : nnz_vec);
             sum[r] = val_t(0);
-            accumulate(sum[r], G.c[r], G.a[r], G.j[r], G.b[r], hi[r]);
+            accumulate(sum[r], G.c[r], G.a[r], G.j[r], G.lo[r], hi[r]);
             jn[r] = G.j[r] + off_t(T) * 4;
             more |= jn[r] < hi[r];
         }
@@ -458,7 +510,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
             v4 a2[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                off_t jl = jn[r] < hi[r] ? jn[r] : (G.b[r] & ~off_t(3));
+                off_t jl = jn[r] < hi[r] ? jn[r] : (G.lo[r] & ~off_t(3));
                 jl = jl < j_max ? jl : j_max;
                 c2[r] = stream_load(reinterpret_cast<const int4v*>(Aj + jl));
                 a2[r] = stream_load(reinterpret_cast<const v4*>(Ax + jl));
@@ -466,7 +518,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
             more = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                accumulate(sum[r], c2[r], a2[r], jn[r], G.b[r], hi[r]);   // (clamped loads are masked by hi)
+                accumulate(sum[r], c2[r], a2[r], jn[r], G.lo[r], hi[r]);   // (clamped loads are masked by hi)
                 jn[r] += off_t(T) * 4;
                 more |= jn[r] < hi[r];
             }
@@ -476,17 +528,19 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
         if (lane == 0) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (local0 + r >= rows) continue;
+                const int row = row_of(g, r);
+                if (row >= rows) continue;
                 if (deferred[r]) {
-                    const unsigned rel = unsigned(local0 + r);
+                    unsigned rel = unsigned(row);
+                    asm volatile("" : "+v"(rel));   // (opaque: the bit masks of the R rows are otherwise precomputed and kept live)
                     atomicOr(&scr.long_map[rel >> 5], 1u << (rel & 31));
                     continue;
                 }
-                if (G.b[r + 1] > nnz_vec) {                // the last (partial) group of the arrays
-                    for (off_t k = (G.b[r] > nnz_vec ? G.b[r] : nnz_vec); k < G.b[r + 1]; ++k)
+                if (G.hi[r] > nnz_vec) {                   // the last (partial) group of the arrays
+                    for (off_t k = (G.lo[r] > nnz_vec ? G.lo[r] : nnz_vec); k < G.hi[r]; ++k)
                         sum[r] += Ax[k] * x[Aj[k]];
                 }
-                scr.s_y[local0 + r] = sum[r];
+                scr.s_y[row] = sum[r];
             }
         }
     };
@@ -524,8 +578,8 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
                 int4v c0, c1;
                 v4 a0, a1;
                 const off_t j1 = j + off_t(kWave) * 4;
-                load_group<off_t, val_t>(j, nnz, Aj, Ax, c0, a0);
-                if (j1 < end) load_group<off_t, val_t>(j1, nnz, Aj, Ax, c1, a1);
+                load_group<val_t>(j, nnz, Aj, Ax, c0, a0);
+                if (j1 < end) load_group<val_t>(j1, nnz, Aj, Ax, c1, a1);
                 else { c1 = int4v{0, 0, 0, 0}; a1 = v4{0, 0, 0, 0}; }
                 accumulate(sum, c0, a0, j, start, end);
                 accumulate(sum, c1, a1, j1, start, end);
@@ -535,7 +589,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
         }
     }
 
-    // ... and a hub row (more than kHugeRow nonzeros: one wave would need many dependent steps) by all four
+    // ... and a hub row (more than kHugeRow nonzeros: one wave would need many dependent steps) by all the
     // waves, partial sums folded through LDS in wave order
     if (any_huge) {
         __shared__ val_t s_part[WAVES];
@@ -555,7 +609,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
                 // R issued before the current ones are consumed, branch-free clamped addresses (a slab past
                 // the row re-reads the row's first line and is masked by hi_v)
                 val_t sum = val_t(0);
-                constexpr int64_t SLAB = int64_t(BLOCK) * 4;                    // (64-bit: may step past 2^31)
+                constexpr int64_t SLAB = int64_t(BLOCK) * 4;                    // (64-bit: the steps may pass 2^31)
                 const off_t hi_v = end < nnz_vec ? end : nnz_vec;
                 const off_t first = start & ~off_t(3);
                 struct Slabs { int4v c[R]; v4 a[R]; };
@@ -609,17 +663,19 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     constexpr int PER16 = 16 / int(sizeof(val_t));
     const val_t alpha = scr.alpha, beta = scr.beta;
     const bool scaled = (alpha != val_t(1)) || (beta != val_t(0));   // uniform
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // (opaque: keeps the sweep's per-thread offsets from being hoisted out of a persistent loop)
     if (!scaled && (reinterpret_cast<uintptr_t>(yc) & 15u) == 0) {
         using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
         const int full = rows / PER16;
-        for (int g = threadIdx.x; g < full; g += BLOCK)
+        for (int g = tid; g < full; g += BLOCK)
             __builtin_nontemporal_store(*reinterpret_cast<const v16*>(scr.s_y + g * PER16),
                                         reinterpret_cast<v16*>(yc + g * PER16));
-        for (int i = full * PER16 + threadIdx.x; i < rows; i += BLOCK) yc[i] = scr.s_y[i];
+        for (int i = full * PER16 + tid; i < rows; i += BLOCK) yc[i] = scr.s_y[i];
     } else if (!scaled) {
-        for (int i = threadIdx.x; i < rows; i += BLOCK) yc[i] = scr.s_y[i];
+        for (int i = tid; i < rows; i += BLOCK) yc[i] = scr.s_y[i];
     } else {
-        for (int i = threadIdx.x; i < rows; i += BLOCK) {
+        for (int i = tid; i < rows; i += BLOCK) {
             val_t v = alpha * scr.s_y[i];
             if (beta != val_t(0)) v += beta * yc[i];
             yc[i] = v;
@@ -631,32 +687,51 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
 // 2 000 near-empty rows and chunks of 100 rows x 120 nonzeros; one width for all of them leaves the second
 // kind walking 16 dependent steps per row.  Three widths (2, 8, 32 lanes: rows of <= 8, 32, 128 nonzeros in
 // one step) from the chunk's own mean row length, read from the bounds already in LDS.
-template <int BLOCK, int T, int R, bool WINDOW, bool ADAPT, typename off_t, typename val_t, typename StageFn>
-__device__ __forceinline__ void chunk_rows_any(int64_t chunk_begin, int64_t chunk_end, off_t nnz,
-                                               const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
+template <int BLOCK, int T, int R, bool WINDOW, bool ADAPT, typename val_t, typename StageFn>
+__device__ __forceinline__ void chunk_rows_any(int64_t chunk_begin, int64_t chunk_end, int32_t nnz,
+                                               const int32_t* __restrict__ Aj,
                                                const val_t* __restrict__ Ax, const val_t* __restrict__ x,
                                                val_t* __restrict__ y, StageFn&& stage,
-                                               const ChunkScratch<off_t, val_t>& scr) {
+                                               const ChunkScratch<val_t>& scr) {
     if constexpr (!ADAPT) {
-        chunk_rows<BLOCK, T, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
+        chunk_rows<BLOCK, T, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
     } else {
         const int rows = int(chunk_end - chunk_begin);
-        const off_t mean = (scr.s_b[rows] - scr.s_b[0]) / off_t(rows > 0 ? rows : 1);   // uniform over the workgroup
-        if (mean <= 16) chunk_rows<BLOCK, 2, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
-        else if (mean <= 64) chunk_rows<BLOCK, 8, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
-        else chunk_rows<BLOCK, 32, R, WINDOW, off_t, val_t>(chunk_begin, chunk_end, nnz, Ap, Aj, Ax, x, y, stage, scr);
+        const int32_t mean = (scr.s_b[rows] - scr.s_b[0]) / int32_t(rows > 0 ? rows : 1);   // uniform over the workgroup
+        if (mean <= 16) chunk_rows<BLOCK, 2, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
+        else if (mean <= 64) chunk_rows<BLOCK, 8, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
+        else chunk_rows<BLOCK, 32, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
+    }
+}
+
+// A chunk whose nonzeros span more than the 32-bit path can index (see kRel32Limit): one wave per row,
+// 4-byte loads, 64-bit indices, results straight to y.  Slow, and only ever reached by matrices with rows
+// of ~10^9 nonzeros; summation order = the fallback kernels' (row_dot.hpp).
+template <int BLOCK, typename val_t>
+__device__ __forceinline__ void chunk_rows_wide(int64_t chunk_begin, int64_t chunk_end, const ApView Ap,
+                                                const int32_t* __restrict__ Aj, const val_t* __restrict__ Ax,
+                                                const val_t* __restrict__ x, val_t* __restrict__ y, val_t alpha,
+                                                val_t beta, int64_t giant_len) {
+    const int lane64 = threadIdx.x & (kWave - 1);
+    for (int64_t row = chunk_begin + threadIdx.x / kWave; row < chunk_end; row += BLOCK / kWave) {   // wave-uniform
+        const int64_t start = Ap.at(row), end = Ap.at(row + 1);
+        val_t sum = val_t(0);
+        if (!(giant_len > 0 && end - start > giant_len))           // (a giant row: 0 here, the slice kernels add it)
+            for (int64_t k = start + lane64; k < end; k += kWave) sum += Ax[k] * x[Aj[k]];
+        sum = vector_reduce<kWave, val_t>(sum);
+        if (lane64 == 0) y[row] = (beta != val_t(0)) ? alpha * sum + beta * y[row] : alpha * sum;
     }
 }
 
 // Rows per workgroup chunk: ~32 K nonzeros (256 KB of fp32 stream) per chunk, a
 // multiple of the rows one pass of the workgroup covers.
 inline int64_t pick_rows_per_chunk(int64_t nnz, int64_t n_rows, int lanes_per_row, int rows_in_flight,
-                                   int block_threads = kBlock, int64_t nnz_per_chunk = 32768) {
+                                   int block_threads = kBlock, int64_t nnz_per_chunk = 32768, int per_cu = 4) {
     const int64_t pass = int64_t(block_threads / lanes_per_row) * rows_in_flight;
     const int64_t mean = n_rows > 0 ? (nnz + n_rows - 1) / n_rows : 1;
     int64_t rows = nnz_per_chunk / (mean > 0 ? mean : 1);
-    // small matrices: prefer >= 4 chunks per CU over long chunks
-    const int64_t fill = (n_rows + int64_t(kCus) * 4 - 1) / (int64_t(kCus) * 4);
+    // small matrices: prefer one chunk per workgroup slot (per_cu a CU) over long chunks
+    const int64_t fill = (n_rows + int64_t(kCus) * per_cu - 1) / (int64_t(kCus) * per_cu);
     if (rows > fill) rows = fill;
     rows = (rows + pass - 1) / pass * pass;
     if (rows < pass) rows = pass;
