@@ -89,6 +89,35 @@ template <typename val_t> struct Semiring<MI355_SEMIRING_MAX_TIMES, val_t> {
 // log_{L+1}(n_rows) + 1 loads long and the probes of a round are spread over L times as many CUs.
 // L = 16 for a few thousand diagonals (latency-bound), smaller L as the diagonals alone fill the chip
 // (L = 1 is the bisection); launch_merge picks L from the measured crossovers.
+// The split of diagonal `diag`, searched by a group of kSearchLanes consecutive lanes (k = lane's index in its
+// group, shift = the group's first lane in the wave).  Every lane of the wave must call; groups whose search has
+// ended probe nothing new.  Returns the rows consumed (lo); the nonzeros consumed are nnz_begin + diag - lo.
+template <int kSearchLanes, typename off_t>
+__device__ __forceinline__ int64_t merge_search_group(int64_t diag, int32_t n_rows, int64_t nnz_begin, int64_t nnz,
+                                                      const off_t* __restrict__ Ap, int k, int shift) {
+    const int64_t count = nnz - nnz_begin;
+    int64_t lo = diag - count > 0 ? diag - count : 0;
+    int64_t hi = diag < n_rows ? diag : n_rows;
+    while (__any(lo < hi)) {                                    // a finished group probes nothing new: c = 0
+        const int64_t n = hi - lo;
+        const bool last = n <= kSearchLanes;                    // every remaining position probed: c is the answer
+        auto probe = [&](int j) { return last ? lo + j : lo + (int64_t(j + 1) * n) / (kSearchLanes + 1); };
+        const int64_t q = probe(k);
+        const int64_t qc = q < hi ? q : hi - 1;                 // clamped into [-1, n_rows): the load is in range
+        const bool below = (q < hi) & (int64_t(Ap[qc + 1]) - nnz_begin <= diag - qc - 1);
+        const int c = __popcll((__ballot(below) >> shift) & ((kSearchLanes == 64 ? ~0ull : (1ull << kSearchLanes) - 1)));
+        if (last) {
+            lo += c;
+            hi = lo;
+        } else {
+            const int64_t new_lo = c > 0 ? probe(c - 1) + 1 : lo;
+            hi = c < kSearchLanes ? probe(c) : hi;
+            lo = new_lo;
+        }
+    }
+    return lo;
+}
+
 template <int kSearchLanes, typename off_t>
 __global__ __launch_bounds__(kBlock) void merge_search_kernel(
     int32_t n_rows, int64_t nnz_begin, int64_t nnz, const off_t* __restrict__ Ap, int64_t tile_items, int64_t n_tiles,
@@ -100,29 +129,10 @@ __global__ __launch_bounds__(kBlock) void merge_search_kernel(
     const int64_t t = t_raw <= n_tiles ? t_raw : n_tiles;       // surplus groups repeat the last diagonal
     const int k = int(gid) & (kSearchLanes - 1);
     const int shift = (threadIdx.x & (kWave - 1)) & ~(kSearchLanes - 1);
-    const int64_t count = nnz - nnz_begin;
-    const int64_t items = int64_t(n_rows) + count;
+    const int64_t items = int64_t(n_rows) + (nnz - nnz_begin);
     int64_t diag = t * tile_items;
     if (diag > items) diag = items;
-    int64_t lo = diag - count > 0 ? diag - count : 0;
-    int64_t hi = diag < n_rows ? diag : n_rows;
-    while (__any(lo < hi)) {                                    // a finished group probes nothing new: c = 0
-        const int64_t n = hi - lo;
-        const bool last = n <= kSearchLanes;                    // every remaining position probed: c is the answer
-        auto probe = [&](int j) { return last ? lo + j : lo + (int64_t(j + 1) * n) / (kSearchLanes + 1); };
-        const int64_t q = probe(k);
-        const int64_t qc = q < hi ? q : hi - 1;                 // clamped into [-1, n_rows): the load is in range
-        const bool below = (q < hi) & (int64_t(Ap[qc + 1]) - nnz_begin <= diag - qc - 1);
-        const int c = __popcll((__ballot(below) >> shift) & ((1ull << kSearchLanes) - 1));
-        if (last) {
-            lo += c;
-            hi = lo;
-        } else {
-            const int64_t new_lo = c > 0 ? probe(c - 1) + 1 : lo;
-            hi = c < kSearchLanes ? probe(c) : hi;
-            lo = new_lo;
-        }
-    }
+    const int64_t lo = merge_search_group<kSearchLanes, off_t>(diag, n_rows, nnz_begin, nnz, Ap, k, shift);
     if (k == 0 && t_raw <= n_tiles) {
         tile_row[t] = int32_t(lo);
         tile_nnz[t] = nnz_begin + diag - lo;
@@ -130,11 +140,15 @@ __global__ __launch_bounds__(kBlock) void merge_search_kernel(
 }
 
 // ---- K7: one run of consecutive tiles per workgroup ---------------------------------
-template <int BLOCK, int IPT, bool VEC, bool WINDOW, int S, typename off_t, typename val_t>
+// SEARCH: the run's tile coordinates are found HERE (16 lanes per diagonal, up to 16 diagonals at once by the
+// whole workgroup) instead of by a search kernel in front: one launch and one kernel boundary fewer per SpMV
+// (the reference has the same option, agent_spmv_orig.cuh:697-719).  The workgroup's first lane group also stores
+// them where the search kernel would have, so plan_merge_coords / MI355_PLAN_REUSE_STRUCTURE see the same arrays.
+template <int BLOCK, int IPT, bool VEC, bool WINDOW, int S, bool SEARCH, typename off_t, typename val_t>
 __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
-    int32_t n_rows, int32_t n_cols, int64_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
+    int32_t n_rows, int32_t n_cols, int64_t nnz_begin, int64_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
-    const int32_t* __restrict__ tile_row, const int64_t* __restrict__ tile_nnz,
+    int32_t* __restrict__ tile_row_g, int64_t* __restrict__ tile_nnz_g, int64_t tile_items,
     int32_t* __restrict__ carry_row, val_t* __restrict__ carry_val, int64_t n_tiles, int32_t tiles_per_super,
     int32_t window_cap, BandHint hint, val_t alpha, val_t beta) {
     constexpr int G = IPT / 4;
@@ -153,6 +167,37 @@ __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
     const int wave = tid / kWave;
     const int64_t first = int64_t(sup) * tiles_per_super;
     const int64_t last = min(first + tiles_per_super, n_tiles);
+
+    // tile coordinates first .. last of this run: from the search kernel's arrays, or searched here
+    constexpr int kMaxRun = 32;                       // (launch_merge: tiles_per_super < kMaxRun when SEARCH)
+    __shared__ int32_t s_tile_row[SEARCH ? kMaxRun + 1 : 1];
+    __shared__ int64_t s_tile_nnz[SEARCH ? kMaxRun + 1 : 1];
+    if constexpr (SEARCH) {
+        const int64_t items = int64_t(n_rows) + (nnz - nnz_begin);
+        const int n_diag = int(last - first) + 1;
+        // one pass of the whole workgroup: 16 lanes per diagonal for up to BLOCK / 16 diagonals, else 8 lanes
+        auto pass = [&](auto lanes_tag) {
+            constexpr int L = decltype(lanes_tag)::value;
+            const int d = tid / L;
+            int64_t diag = (first + min(d, n_diag - 1)) * tile_items;           // surplus groups repeat the last diagonal
+            if (diag > items) diag = items;
+            const int64_t lo = merge_search_group<L, off_t>(diag, n_rows, nnz_begin, nnz, Ap, tid & (L - 1),
+                                                            (tid & (kWave - 1)) & ~(L - 1));
+            if ((tid & (L - 1)) == 0 && d < n_diag) {
+                s_tile_row[d] = int32_t(lo);
+                s_tile_nnz[d] = nnz_begin + diag - lo;
+                if (d < n_diag - 1 || last == n_tiles) {                        // (the next run stores its own first one)
+                    tile_row_g[first + d] = int32_t(lo);
+                    tile_nnz_g[first + d] = nnz_begin + diag - lo;
+                }
+            }
+        };
+        if (n_diag <= BLOCK / 16) pass(std::integral_constant<int, 16>{});      // (uniform over the workgroup)
+        else pass(std::integral_constant<int, 8>{});
+        __syncthreads();
+    }
+    const int32_t* const tile_row = SEARCH ? s_tile_row - first : tile_row_g;   // (indexed by absolute tile number below)
+    const int64_t* const tile_nnz = SEARCH ? s_tile_nnz - first : tile_nnz_g;
 
     int x0 = tile_row[first], x1 = tile_row[first + 1];
     int64_t y0 = tile_nnz[first], y1 = tile_nnz[first + 1];
@@ -414,6 +459,19 @@ __global__ __launch_bounds__(kBlock) void merge_fixup_kernel(
 }
 
 // ---- host side -----------------------------------------------------------------------
+// Whether the tile kernel searches its own coordinates (MI355_MERGE_FUSED = 0 | 1 overrides): always, when a run
+// is short enough for the workgroup to search all its diagonals in two passes.
+static bool merge_search_in_kernel(const Plan& p) {
+    if (p.knob.merge_fused == 0) return false;
+    if (p.tiles_per_super + 1 > 32) return false;         // (one pass of 256 threads searches 32 diagonals)
+    if (p.knob.merge_fused > 0) return true;
+    // Measured (us, fused / search kernel in front): web-Google stand-in (1 473 runs) 46.6 / 49.5, cant stand-in 19.3 /
+    // 20.3 — but S32-band (4 233 runs of 16 tiles) 282 / 258 and R-MAT-24 (8 700 runs) 2 516 / 2 483: on a grid of
+    // many rounds every workgroup pays the search's chain of dependent loads at its start, and the search kernel's
+    // ~9 us are a few per cent.  Fused where the grid is at most ~two rounds of the chip.
+    return p.n_super <= int64_t(kCus) * 8;
+}
+
 void shape_merge(Plan& p) {
     // tuning knobs: MI355_MERGE_TPS = tiles per run (and MI355_SPMV_WINDOW = 0|1, analyze.hip)
     // 256 threads x 8 items or (MI355_MERGE_BLOCK=512) 512 threads x 4 items: the same 2 044-item tiles
@@ -441,7 +499,7 @@ void shape_merge(Plan& p) {
         p.window_elems = (tps * p.tile_items >= 8192) ? pick_window_elems(p, rows_per_run) : 0;
         if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }   // several bands: this kind keeps to global gathers
     }
-    p.n_kernels = p.n_super > 1 ? 3 : 2;
+    p.n_kernels = (p.n_super > 1 ? 2 : 1) + ((merge_search_in_kernel(p) && p.block_threads == kBlock) ? 0 : 1);
     p.coords_valid = false;
     snprintf(p.main_kernel, sizeof(p.main_kernel), "merge_tile_kernel");
 }
@@ -452,7 +510,11 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
     const bool reuse = (p.flags & MI355_PLAN_REUSE_STRUCTURE) && p.coords_valid;
-    if (!reuse) {
+    const bool vec = aligned && p.nnz >= 4;
+    const bool wide = p.block_threads == kWideBlock && p.semiring == MI355_SEMIRING_PLUS_TIMES;
+    // the tile kernel finds its run's coordinates itself (no search kernel in front) on the 16-byte path with 256 threads
+    const bool fused = !reuse && vec && !wide && merge_search_in_kernel(p);
+    if (!reuse && !fused) {
         const int64_t diagonals = p.n_tiles + 1;
         // measured (us, L = 1 / 4 / 16): 2 946 diagonals 7.3 / 6.0 / 4.4, 68 K 11.9 / 8.5 / 13.3, 139 K 14.0 / 16.0 / 30.9
         const int forced = p.knob.merge_search_lanes;
@@ -468,24 +530,29 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
             hipLaunchKernelGGL((merge_search_kernel<1, off_t>), dim3(g), dim3(kBlock), 0, s, p.n_rows, p.nnz_begin, p.nnz, Ap,
                                p.tile_items, p.n_tiles, p.tile_row, p.tile_nnz);
         MI355_HIP_TRY(hipGetLastError());
-        p.coords_valid = true;
     }
+    if (!reuse) p.coords_valid = true;
     const int32_t cap = (aligned && p.nnz >= 4) ? (int32_t)p.window_elems : 0;
     const size_t dyn = size_t(cap) * sizeof(val_t);
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
     const dim3 grid((unsigned)p.n_super);
-    const bool wide = p.block_threads == kWideBlock && p.semiring == MI355_SEMIRING_PLUS_TIMES;
-#define MI355_MERGE_ARGS dyn, s, p.n_rows, p.n_cols, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz, p.carry_row, \
+#define MI355_MERGE_ARGS dyn, s, p.n_rows, p.n_cols, p.nnz_begin, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz, p.tile_items, p.carry_row, \
                        static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super, cap, hint, (val_t)p.alpha, (val_t)p.beta
 #define MI355_MERGE_LAUNCH(VEC_, WIN_, S_)                                                                    \
     do {                                                                                                      \
         if constexpr (S_ == MI355_SEMIRING_PLUS_TIMES) {                                                      \
             if (wide) {                                                                                       \
-                hipLaunchKernelGGL((merge_tile_kernel<kWideBlock, 4, VEC_, WIN_, S_, off_t, val_t>), grid, dim3(kWideBlock), MI355_MERGE_ARGS); \
+                hipLaunchKernelGGL((merge_tile_kernel<kWideBlock, 4, VEC_, WIN_, S_, false, off_t, val_t>), grid, dim3(kWideBlock), MI355_MERGE_ARGS); \
                 break;                                                                                        \
             }                                                                                                 \
         }                                                                                                     \
-        hipLaunchKernelGGL((merge_tile_kernel<kBlock, 8, VEC_, WIN_, S_, off_t, val_t>), grid, dim3(kBlock), MI355_MERGE_ARGS); \
+        if constexpr (VEC_) {                                                                                 \
+            if (fused) {                                                                                      \
+                hipLaunchKernelGGL((merge_tile_kernel<kBlock, 8, VEC_, WIN_, S_, true, off_t, val_t>), grid, dim3(kBlock), MI355_MERGE_ARGS); \
+                break;                                                                                        \
+            }                                                                                                 \
+        }                                                                                                     \
+        hipLaunchKernelGGL((merge_tile_kernel<kBlock, 8, VEC_, WIN_, S_, false, off_t, val_t>), grid, dim3(kBlock), MI355_MERGE_ARGS); \
     } while (0)
 #define MI355_MERGE_SEMIRING(S_)                                                    \
     do {                                                                            \
@@ -500,7 +567,6 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
             MI355_HIP_TRY(hipGetLastError());                                       \
         }                                                                           \
     } while (0)
-    const bool vec = aligned && p.nnz >= 4;
     switch (p.semiring) {
         case MI355_SEMIRING_PLUS_TIMES: MI355_MERGE_SEMIRING(MI355_SEMIRING_PLUS_TIMES); break;
         case MI355_SEMIRING_MIN_PLUS:   MI355_MERGE_SEMIRING(MI355_SEMIRING_MIN_PLUS); break;
