@@ -66,12 +66,15 @@ enum { MI355_VAL_F32 = 0, MI355_VAL_F64 = 1 };
 /* semirings of the generalized merge kind.  The reference's
  * SpMV_merge_based_generalized takes a functor_t with initialize / combine / reduce
  * (include/spmv/merge_genl/merge_genl.cuh:19-38; CPU twin include/spmv/cpu_navie.hpp:20-34)
- * and ships (+, *); a C ABI enumerates them instead:
+ * and ships (+, *); a C ABI cannot take a C++ functor and enumerates them instead:
  *   PLUS_TIMES  y[r] = sum_k  Ax[k] * x[Aj[k]]           (identity 0)      — every other entry point
  *   MIN_PLUS    y[r] = min_k (Ax[k] + x[Aj[k]])          (identity +inf)   — shortest-path relaxation
- *   MAX_TIMES   y[r] = max_k (Ax[k] * x[Aj[k]])          (identity -inf)   — or-and on {0,1}, widest path */
+ *   MAX_TIMES   y[r] = max_k (Ax[k] * x[Aj[k]])          (identity -inf)   — widest / most reliable path
+ *   MAX_PLUS    y[r] = max_k (Ax[k] + x[Aj[k]])          (identity -inf)   — longest path, Viterbi
+ *   OR_AND      y[r] = OR_k (Ax[k] != 0 AND x[Aj[k]] != 0) as 1.0 / 0.0  (identity 0)
+ *                                                                         — boolean SpMV: one BFS / reachability step */
 enum { MI355_SEMIRING_PLUS_TIMES = 0, MI355_SEMIRING_MIN_PLUS = 1, MI355_SEMIRING_MAX_TIMES = 2,
-       MI355_SEMIRING_COUNT = 3 };
+       MI355_SEMIRING_MAX_PLUS = 3, MI355_SEMIRING_OR_AND = 4, MI355_SEMIRING_COUNT = 5 };
 
 /* plan flags */
 enum {
@@ -132,6 +135,18 @@ typedef struct mi355_spmv_plan mi355_spmv_plan;
 int mi355_spmv_plan_create(mi355_spmv_plan** plan, int kind, int off_type, int val_type,
                            int32_t n_rows, int32_t n_cols, int64_t nnz, const void* Ap,
                            const int32_t* Aj, int flags);
+/* The reference's operator has separate matrix / x / y value types (include/spmv.h:29-34; its generalized merge
+ * kind computes in the y type, merge_genl.cuh:29-31).  Built here: all three equal (every kind), and an fp32
+ * MATRIX under fp64 x and y for the MERGE kind — values are widened as they meet x, products and sums are fp64
+ * (the mixed-precision case that halves the matrix stream).  Other combinations return MI355_SPMV_ENOTSUP.
+ * execute then takes Ax as float*, x / y as double*.                                                         */
+int mi355_spmv_plan_create_typed(mi355_spmv_plan** plan, int kind, int off_type, int mat_type, int x_type,
+                                 int y_type, int32_t n_rows, int32_t n_cols, int64_t nnz, const void* Ap,
+                                 const int32_t* Aj, int flags);
+int mi355_spmv_merge_f32mat_f64vec_i32(int32_t n_rows, int32_t n_cols, int32_t nnz, const int32_t* Ap,
+                                       const int32_t* Aj, const float* Ax, const double* x, double* y, void* stream);
+int mi355_spmv_merge_f32mat_f64vec_i64(int32_t n_rows, int32_t n_cols, int64_t nnz, const int64_t* Ap,
+                                       const int32_t* Aj, const float* Ax, const double* x, double* y, void* stream);
 int mi355_spmv_plan_execute(mi355_spmv_plan* plan, const void* Ax, const void* x, void* y,
                             void* stream);
 int mi355_spmv_plan_destroy(mi355_spmv_plan* plan);

@@ -62,6 +62,15 @@ class Oracle:
         getattr(self.lib, f"oracle_spmv_serial_{o}_{v}")(C.c_int32(n), _p(Ap), _p(Aj), _p(Ax), _p(x), _p(y))
         return y
 
+    def spmv_serial_mixed(self, Ap, Aj, Ax, x):
+        """fp32 matrix, fp64 x -> fp64 y, serial CSR order (cpu_navie.hpp:5-17 as <float, double, double>)."""
+        assert Ax.dtype == np.float32 and x.dtype == np.float64 and Aj.dtype == np.int32
+        n = len(Ap) - 1
+        o = "i32" if Ap.dtype == np.int32 else "i64"
+        y = np.empty(n, dtype=np.float64)
+        getattr(self.lib, f"oracle_spmv_serial_mixed_{o}")(C.c_int32(n), _p(Ap), _p(Aj), _p(Ax), _p(x), _p(y))
+        return y
+
     def spmv_genl_serial(self, semiring, Ap, Aj, Ax, x):
         """Generalized serial SpMV (cpu_navie.hpp:20-34); semiring 0 = (+,*), 1 = (min,+), 2 = (max,*)."""
         n = self._check(Ap, Aj, Ax, x)
@@ -179,6 +188,16 @@ class Ref:
         nnz = _OFF[o][1](int(Ap[-1]))
         getattr(self.lib, f"ref_spmv_genl_cpu_{o}_{v}")(
             C.c_int(semiring), C.c_int(n), C.c_int(n_cols), nnz, _p(Ap), _p(Aj), _p(Ax), _p(x), _p(y))
+        return y
+
+    def spmv_cpu_mixed(self, n_cols, Ap, Aj, Ax, x):
+        """The reference's SpMV_cpu_navie<int, off, float, double, double>."""
+        assert Ax.dtype == np.float32 and x.dtype == np.float64
+        o = "i32" if Ap.dtype == np.int32 else "i64"
+        n = len(Ap) - 1
+        y = np.empty(n, dtype=np.float64)
+        nnz = _OFF[o][1](int(Ap[-1]))
+        getattr(self.lib, f"ref_spmv_cpu_mixed_{o}")(C.c_int(n), C.c_int(n_cols), nnz, _p(Ap), _p(Aj), _p(Ax), _p(x), _p(y))
         return y
 
     def spmv_cpu(self, n_cols, Ap, Aj, Ax, x):

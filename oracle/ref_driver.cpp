@@ -42,6 +42,16 @@ template <typename V> struct MaxTimes {
     static V combine(V a, V x) { return a * x; }
     static V reduce(V u, V v) { return u < v ? v : u; }
 };
+template <typename V> struct MaxPlus {
+    static V initialize() { return -std::numeric_limits<V>::infinity(); }
+    static V combine(V a, V x) { return a + x; }
+    static V reduce(V u, V v) { return u < v ? v : u; }
+};
+template <typename V> struct OrAnd {
+    static V initialize() { return V(0); }
+    static V combine(V a, V x) { return (a != V(0) && x != V(0)) ? V(1) : V(0); }
+    static V reduce(V u, V v) { return (u != V(0) || v != V(0)) ? V(1) : V(0); }
+};
 template <typename off_t, typename val_t>
 struct Held {
     csr_t<int, off_t, val_t> csr;
@@ -79,13 +89,27 @@ extern "C" {
             SpMV_genl_cpu_navie<PlusTimes<VAL>, int, OFF, VAL, VAL, VAL>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y); \
         else if (semiring == 1)                                                                \
             SpMV_genl_cpu_navie<MinPlus<VAL>, int, OFF, VAL, VAL, VAL>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);   \
-        else                                                                                   \
+        else if (semiring == 2)                                                                \
             SpMV_genl_cpu_navie<MaxTimes<VAL>, int, OFF, VAL, VAL, VAL>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);  \
+        else if (semiring == 3)                                                                \
+            SpMV_genl_cpu_navie<MaxPlus<VAL>, int, OFF, VAL, VAL, VAL>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);   \
+        else                                                                                   \
+            SpMV_genl_cpu_navie<OrAnd<VAL>, int, OFF, VAL, VAL, VAL>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);     \
     }                                                                                          \
     void ref_spmv_cpu_##SUF(int n_rows, int n_cols, OFF nnz, const OFF* Ap, const int* Aj,     \
                             const VAL* Ax, const VAL* x, VAL* y) {                             \
         SpMV_cpu_navie<int, OFF, VAL, VAL, VAL>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);        \
     }
+
+// The reference's serial check with an fp32 MATRIX under fp64 vectors (its template keeps the three value types
+// apart, include/spmv.h:29-34): pins the oracle's restatement of that case.
+#define REF_MIXED(SUF, OFF)                                                                    \
+    void ref_spmv_cpu_mixed_##SUF(int n_rows, int n_cols, OFF nnz, const OFF* Ap, const int* Aj, \
+                                  const float* Ax, const double* x, double* y) {               \
+        SpMV_cpu_navie<int, OFF, float, double, double>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y); \
+    }
+REF_MIXED(i32, int)
+REF_MIXED(i64, long long)
 
 REF_TYPED(i32_f32, int, float)
 REF_TYPED(i32_f64, int, double)

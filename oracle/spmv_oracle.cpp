@@ -55,17 +55,21 @@ void spmv_serial(int32_t row_begin, int32_t row_end, const off_t* Ap,
 
 // Generalized serial SpMV — restates include/spmv/cpu_navie.hpp:20-34:
 //   sum = functor::initialize(); sum = functor::reduce(sum, functor::combine(Ax[k], x[Aj[k]])); y[row] = sum
-// with the semirings the C ABI enumerates (include/mi355_spmv.h): 0 = (+, *), 1 = (min, +), 2 = (max, *).
+// with the semirings the C ABI enumerates (include/mi355_spmv.h): 0 = (+, *), 1 = (min, +), 2 = (max, *),
+// 3 = (max, +), 4 = (or, and) on 0.0 / 1.0.
 template <typename off_t, typename val_t>
 void spmv_genl_serial(int semiring, int32_t n_rows, const off_t* Ap, const int32_t* Aj, const val_t* Ax,
                       const val_t* x, val_t* y) {
     const val_t inf = std::numeric_limits<val_t>::infinity();
     for (int32_t row = 0; row < n_rows; ++row) {
-        val_t sum = semiring == 0 ? val_t(0) : (semiring == 1 ? inf : -inf);
+        val_t sum = (semiring == 0 || semiring == 4) ? val_t(0) : (semiring == 1 ? inf : -inf);
         for (off_t k = Ap[row]; k < Ap[row + 1]; ++k) {
             if (semiring == 0) sum = sum + Ax[k] * x[Aj[k]];
             else if (semiring == 1) { const val_t v = Ax[k] + x[Aj[k]]; sum = v < sum ? v : sum; }
-            else { const val_t v = Ax[k] * x[Aj[k]]; sum = sum < v ? v : sum; }
+            else if (semiring == 2) { const val_t v = Ax[k] * x[Aj[k]]; sum = sum < v ? v : sum; }
+            else if (semiring == 3) { const val_t v = Ax[k] + x[Aj[k]]; sum = sum < v ? v : sum; }
+            else { const val_t v = (Ax[k] != val_t(0) && x[Aj[k]] != val_t(0)) ? val_t(1) : val_t(0);
+                   sum = (sum != val_t(0) || v != val_t(0)) ? val_t(1) : val_t(0); }
         }
         y[row] = sum;
     }
@@ -559,6 +563,20 @@ extern "C" {
                                        int block_threads, int ipt) {                           \
         spmv_merge_order<OFF, VAL>(n_rows, Ap, Aj, Ax, x, y, block_threads, ipt);              \
     }
+
+// fp32 matrix under fp64 vectors (cpu_navie.hpp:5-17 instantiated <float, double, double>): the product is taken in
+// the promoted type (double), the sum kept in vec_y_value_t (double), serial order.
+#define ORACLE_MIXED(SUF, OFF)                                                                 \
+    void oracle_spmv_serial_mixed_##SUF(int32_t n_rows, const OFF* Ap, const int32_t* Aj,      \
+                                        const float* Ax, const double* x, double* y) {         \
+        for (int32_t row = 0; row < n_rows; ++row) {                                           \
+            double sum = 0.0;                                                                  \
+            for (OFF k = Ap[row]; k < Ap[row + 1]; ++k) sum += Ax[k] * x[Aj[k]];               \
+            y[row] = sum;                                                                      \
+        }                                                                                      \
+    }
+ORACLE_MIXED(i32, int32_t)
+ORACLE_MIXED(i64, int64_t)
 
 ORACLE_TYPED(i32_f32, int32_t, float)
 ORACLE_TYPED(i32_f64, int32_t, double)

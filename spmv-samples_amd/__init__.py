@@ -16,4 +16,4 @@ Contents (only what the hot path needs):
     dist.py    row-block sharding + allgatherv(y) for one process per GPU
 """
 from . import capi, dist, synth  # noqa: F401
-from .capi import DistPlan, Plan, PlanShape, spmv, spmv_genl  # noqa: F401
+from .capi import DistPlan, Plan, PlanShape, spmv, spmv_genl, spmv_mixed  # noqa: F401

@@ -21,7 +21,7 @@ LABELS = {"hip_vector": "vector", "hip_merge": "merge", "hip_light": "light"}
 OFF_TYPES = {torch.int32: (0, "i32"), torch.int64: (1, "i64")}
 VAL_TYPES = {torch.float32: (0, "f32"), torch.float64: (1, "f64")}
 PLAN_REUSE_STRUCTURE = 1
-SEMIRINGS = {"plus_times": 0, "min_plus": 1, "max_times": 2}
+SEMIRINGS = {"plus_times": 0, "min_plus": 1, "max_times": 2, "max_plus": 3, "or_and": 4}
 
 EXPORTS = (
     ["mi355_spmv_%s_%s_%s" % (k, o, v) for k in KINDS for o in ("i32", "i64") for v in ("f32", "f64")]
@@ -31,7 +31,8 @@ EXPORTS = (
        "mi355_spmv_plan_get_info", "mi355_spmv_stream_synchronize", "mi355_spmv_plan_merge_coords", "mi355_spmv_version",
        "mi355_spmv_status_string", "mi355_spmv_last_error", "mi355_spmv_device_count"]
     + ["mi355_spmv_plan_get_shape", "mi355_spmv_plan_partition", "mi355_spmv_plan_create_block",
-       "mi355_spmv_knobs_reload"]
+       "mi355_spmv_knobs_reload", "mi355_spmv_plan_create_typed", "mi355_spmv_merge_f32mat_f64vec_i32",
+       "mi355_spmv_merge_f32mat_f64vec_i64"]
     + ["mi355_spmv_dist_" + n for n in ("create_local", "unique_id", "create_rank", "scatter_values", "replicate_x",
                                         "execute", "set_alpha_beta", "parts", "cuts", "part_info", "device_y", "device_x",
                                         "destroy")]
@@ -83,6 +84,8 @@ def lib():
         L.mi355_spmv_last_error.restype = C.c_char_p
         L.mi355_spmv_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int32,
                                              C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        L.mi355_spmv_plan_create_typed.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
         L.mi355_spmv_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi355_spmv_plan_destroy.argtypes = [C.c_void_p]
         L.mi355_spmv_plan_set_semiring.argtypes = [C.c_void_p, C.c_int]
@@ -158,6 +161,20 @@ def spmv(kind, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream=None):
     return y
 
 
+def spmv_mixed(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream=None):
+    """One-shot merge-path SpMV with an fp32 matrix under fp64 vectors (mi355_spmv_merge_f32mat_f64vec_*)."""
+    _require_device(Ap, Aj, Ax, x, y)
+    if Aj.dtype != torch.int32 or Ax.dtype != torch.float32 or x.dtype != torch.float64 or y.dtype != torch.float64:
+        raise TypeError("Aj int32, Ax float32, x and y float64")
+    o = OFF_TYPES[Ap.dtype][1]
+    fn = getattr(lib(), "mi355_spmv_merge_f32mat_f64vec_%s" % o)
+    nnz_c = C.c_int32(nnz) if o == "i32" else C.c_int64(nnz)
+    st = fn(C.c_int32(n_rows), C.c_int32(n_cols), nnz_c, C.c_void_p(Ap.data_ptr()), C.c_void_p(Aj.data_ptr()),
+            C.c_void_p(Ax.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), _stream_ptr(stream))
+    _check(st, "mi355_spmv_merge_f32mat_f64vec_%s" % o)
+    return y
+
+
 def spmv_genl(semiring, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream=None):
     """Generalized merge-path SpMV: the reference's SpMV_merge_based_generalized
     (include/spmv/merge_genl/merge_genl.cuh:41-79) with the semiring as an argument."""
@@ -180,7 +197,10 @@ class Plan:
     """Scratch + launch shapes kept across calls (mi355_spmv_plan_*).  Holds
     references to Ap and Aj so they outlive the plan."""
 
-    def __init__(self, kind, n_rows, n_cols, nnz, Ap, Aj, val_dtype, flags=0):
+    def __init__(self, kind, n_rows, n_cols, nnz, Ap, Aj, val_dtype, flags=0, mat_dtype=None):
+        """val_dtype: the type of x and y (and of all arithmetic).  mat_dtype: the type the matrix values are stored
+        in — None = val_dtype; torch.float32 under torch.float64 vectors is built for the merge kind
+        (mi355_spmv_plan_create_typed; the reference's operator keeps the three value types apart, spmv.h:29-34)."""
         kind = LABELS.get(kind, kind)
         if kind not in KINDS:
             raise ValueError('SpMV kind "%s" is NOT SUPPORTED' % kind)
@@ -189,16 +209,24 @@ class Plan:
             raise TypeError("Aj must be int32")
         self.kind, self.n_rows, self.n_cols, self.nnz = kind, n_rows, n_cols, nnz
         self.Ap, self.Aj, self.val_dtype = Ap, Aj, val_dtype
+        self.mat_dtype = mat_dtype if mat_dtype is not None else val_dtype
         self._h = C.c_void_p()
-        st = lib().mi355_spmv_plan_create(C.byref(self._h), KINDS[kind], OFF_TYPES[Ap.dtype][0],
-                                          VAL_TYPES[val_dtype][0], n_rows, n_cols, nnz,
-                                          C.c_void_p(Ap.data_ptr()), C.c_void_p(Aj.data_ptr()), flags)
-        _check(st, "mi355_spmv_plan_create")
+        if self.mat_dtype == val_dtype:
+            st = lib().mi355_spmv_plan_create(C.byref(self._h), KINDS[kind], OFF_TYPES[Ap.dtype][0],
+                                              VAL_TYPES[val_dtype][0], n_rows, n_cols, nnz,
+                                              C.c_void_p(Ap.data_ptr()), C.c_void_p(Aj.data_ptr()), flags)
+            _check(st, "mi355_spmv_plan_create")
+        else:
+            st = lib().mi355_spmv_plan_create_typed(C.byref(self._h), KINDS[kind], OFF_TYPES[Ap.dtype][0],
+                                                    VAL_TYPES[self.mat_dtype][0], VAL_TYPES[val_dtype][0],
+                                                    VAL_TYPES[val_dtype][0], n_rows, n_cols, nnz,
+                                                    C.c_void_p(Ap.data_ptr()), C.c_void_p(Aj.data_ptr()), flags)
+            _check(st, "mi355_spmv_plan_create_typed")
 
     def execute(self, Ax, x, y, stream=None):
         """Asynchronous on `stream` (default: torch's current stream)."""
         _require_device(Ax, x, y)
-        if Ax.dtype != self.val_dtype or x.dtype != self.val_dtype or y.dtype != self.val_dtype:
+        if Ax.dtype != getattr(self, "mat_dtype", self.val_dtype) or x.dtype != self.val_dtype or y.dtype != self.val_dtype:
             raise TypeError("value type differs from the plan's")
         if Ax.numel() < self.nnz or x.numel() < self.n_cols or y.numel() < self.n_rows:
             raise ValueError("operand shorter than the plan's sizes")

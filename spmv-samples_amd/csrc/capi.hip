@@ -111,7 +111,10 @@ static int execute_typed(Plan& p, const void* Ax, const void* x, void* y, hipStr
     val_t* yy = static_cast<val_t*>(y);
     switch (p.kind) {
         case MI355_KIND_VECTOR: return launch_vector<off_t, val_t>(p, Ap, ax, xx, yy, s);
-        case MI355_KIND_MERGE:  return launch_merge<off_t, val_t>(p, Ap, ax, xx, yy, s);
+        case MI355_KIND_MERGE:
+            if constexpr (sizeof(val_t) == 8)
+                if (p.mat_type == MI355_VAL_F32) return launch_merge<off_t, val_t, float>(p, Ap, static_cast<const float*>(Ax), xx, yy, s);
+            return launch_merge<off_t, val_t, val_t>(p, Ap, ax, xx, yy, s);
         case MI355_KIND_LIGHT:  return launch_light<off_t, val_t>(p, Ap, ax, xx, yy, s);
     }
     set_error("unknown kind %d", p.kind);
@@ -214,6 +217,7 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
     memset(static_cast<void*>(&p), 0, sizeof(p));
     p.knob = knobs();
     p.kind = kind; p.off_type = off_type; p.val_type = val_type; p.flags = flags;
+    p.mat_type = val_type;
     p.n_rows = n_rows; p.n_cols = n_cols; p.nnz = nnz; p.Ap = Ap; p.Aj = Aj;
     p.nnz_begin = blk ? blk->phase : 0;
     p.nnz_read = nnz;
@@ -310,6 +314,27 @@ int mi355_spmv_plan_create_block(mi355_spmv_plan** out, int kind, int off_type, 
     BlockSpec blk{whole, row_begin, chunk_begin, n_chunks, nnz_begin_whole, int(nnz_begin_whole & 3)};
     if (n_rows == 0) { blk.phase = 0; nnz_end = 0; }   // an empty block owns no element of its view
     return plan_create_impl(out, kind, off_type, val_type, n_rows, n_cols, nnz_end, Ap, Aj, flags, &blk);
+}
+
+int mi355_spmv_plan_create_typed(mi355_spmv_plan** out, int kind, int off_type, int mat_type, int x_type, int y_type,
+                                 int32_t n_rows, int32_t n_cols, int64_t nnz, const void* Ap, const int32_t* Aj, int flags) {
+    g_err[0] = 0;
+    if (out) *out = nullptr;
+    const auto known = [](int t) { return t == MI355_VAL_F32 || t == MI355_VAL_F64; };
+    if (!known(mat_type) || !known(x_type) || !known(y_type)) { set_error("plan_create_typed: unknown value type"); return MI355_SPMV_EINVAL; }
+    if (x_type != y_type) { set_error("plan_create_typed: x and y of different types are not built"); return MI355_SPMV_ENOTSUP; }
+    if (mat_type == x_type) return plan_create_impl(out, kind, off_type, x_type, n_rows, n_cols, nnz, Ap, Aj, flags, nullptr);
+    if (!(mat_type == MI355_VAL_F32 && x_type == MI355_VAL_F64)) {
+        set_error("plan_create_typed: the only mixed combination built is an fp32 matrix under fp64 vectors");
+        return MI355_SPMV_ENOTSUP;
+    }
+    if (kind != MI355_KIND_MERGE) {
+        set_error("plan_create_typed: mixed value types are built for the merge kind only (the kind the reference generalizes)");
+        return MI355_SPMV_ENOTSUP;
+    }
+    const int st = plan_create_impl(out, kind, off_type, x_type, n_rows, n_cols, nnz, Ap, Aj, flags, nullptr);
+    if (st == MI355_SPMV_OK) (*out)->p.mat_type = mat_type;
+    return st;
 }
 
 int mi355_spmv_plan_get_shape(const mi355_spmv_plan* h, mi355_spmv_plan_shape* sh) {
@@ -474,6 +499,21 @@ MI355_SPMV_DEFINE_GENL(i32_f32, int32_t, MI355_OFF_I32, float, MI355_VAL_F32)
 MI355_SPMV_DEFINE_GENL(i32_f64, int32_t, MI355_OFF_I32, double, MI355_VAL_F64)
 MI355_SPMV_DEFINE_GENL(i64_f32, int64_t, MI355_OFF_I64, float, MI355_VAL_F32)
 MI355_SPMV_DEFINE_GENL(i64_f64, int64_t, MI355_OFF_I64, double, MI355_VAL_F64)
+
+#define MI355_SPMV_DEFINE_MIXED(SUF, OFF, OFFENUM)                                                            \
+    int mi355_spmv_merge_f32mat_f64vec_##SUF(int32_t n_rows, int32_t n_cols, OFF nnz, const OFF* Ap,             \
+                                            const int32_t* Aj, const float* Ax, const double* x, double* y, void* st) { \
+        mi355_spmv_plan* plan = nullptr;                                                                         \
+        int rc = mi355_spmv_plan_create_typed(&plan, MI355_KIND_MERGE, OFFENUM, MI355_VAL_F32, MI355_VAL_F64,    \
+                                              MI355_VAL_F64, n_rows, n_cols, (int64_t)nnz, Ap, Aj, MI355_PLAN_DEFAULT); \
+        if (rc != MI355_SPMV_OK) return rc;                                                                      \
+        rc = mi355_spmv_plan_execute(plan, Ax, x, y, st);                                                        \
+        if (rc == MI355_SPMV_OK) rc = mi355_spmv_stream_synchronize(st);                                         \
+        const int rc2 = mi355_spmv_plan_destroy(plan);                                                           \
+        return rc != MI355_SPMV_OK ? rc : rc2;                                                                   \
+    }
+MI355_SPMV_DEFINE_MIXED(i32, int32_t, MI355_OFF_I32)
+MI355_SPMV_DEFINE_MIXED(i64, int64_t, MI355_OFF_I64)
 
 MI355_SPMV_DEFINE_KIND(vector, MI355_KIND_VECTOR)
 MI355_SPMV_DEFINE_KIND(merge, MI355_KIND_MERGE)

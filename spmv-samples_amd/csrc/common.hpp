@@ -73,7 +73,8 @@ const Knobs& knobs();          // parsed on first use
 void knobs_reload();
 
 struct Plan {
-    int kind, off_type, val_type, flags;
+    int kind, off_type, val_type, flags;   // val_type: the type of x, y and of all arithmetic
+    int mat_type;              // the type the matrix values are stored in (= val_type, or F32 under F64 vectors: MERGE)
     int32_t n_rows, n_cols;
     int64_t nnz;               // END offset of the nonzeros: Ap[n_rows] (= their count unless nnz_begin > 0)
     int64_t nnz_read;          // elements of Aj / Ax the 16-byte loads may touch: nnz, or nnz rounded up to a multiple
@@ -151,8 +152,8 @@ int allow_dynamic_lds(const void* kernel, size_t bytes);
 // kernel launchers (one translation unit per kind)
 template <typename off_t, typename val_t>
 int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s);
-template <typename off_t, typename val_t>
-int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s);
+template <typename off_t, typename val_t, typename mat_t>
+int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_t* y, hipStream_t s);
 template <typename off_t, typename val_t>
 int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s);
 

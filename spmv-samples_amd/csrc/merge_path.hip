@@ -80,6 +80,17 @@ template <typename val_t> struct Semiring<MI355_SEMIRING_MAX_TIMES, val_t> {
     __device__ static __forceinline__ val_t reduce(val_t u, val_t v) { return u < v ? v : u; }
 };
 
+template <typename val_t> struct Semiring<MI355_SEMIRING_MAX_PLUS, val_t> {
+    __device__ static __forceinline__ val_t identity() { return val_t(-INFINITY); }
+    __device__ static __forceinline__ val_t combine(val_t a, val_t x) { return a + x; }
+    __device__ static __forceinline__ val_t reduce(val_t u, val_t v) { return u < v ? v : u; }
+};
+template <typename val_t> struct Semiring<MI355_SEMIRING_OR_AND, val_t> {   // booleans carried as 0.0 / 1.0
+    __device__ static __forceinline__ val_t identity() { return val_t(0); }
+    __device__ static __forceinline__ val_t combine(val_t a, val_t x) { return (a != val_t(0) && x != val_t(0)) ? val_t(1) : val_t(0); }
+    __device__ static __forceinline__ val_t reduce(val_t u, val_t v) { return (u != val_t(0) || v != val_t(0)) ? val_t(1) : val_t(0); }
+};
+
 // ---- K6: tile start coordinates ------------------------------------------------
 // The split of diagonal d is the first p in [lo, hi] with Ap[p + 1] > d - p - 1.  The reference finds it
 // by bisection, one thread per diagonal (thread_search.cuh:15-49): ~log2(n_rows) DEPENDENT loads, and the
@@ -144,15 +155,19 @@ __global__ __launch_bounds__(kBlock) void merge_search_kernel(
 // whole workgroup) instead of by a search kernel in front: one launch and one kernel boundary fewer per SpMV
 // (the reference has the same option, agent_spmv_orig.cuh:697-719).  The workgroup's first lane group also stores
 // them where the search kernel would have, so plan_merge_coords / MI355_PLAN_REUSE_STRUCTURE see the same arrays.
-template <int BLOCK, int IPT, bool VEC, bool WINDOW, int S, bool SEARCH, typename off_t, typename val_t>
+// mat_t: the type the matrix values are STORED in — val_t, or float under double vectors (the reference keeps the
+// matrix / x / y types apart, include/spmv.h:29-34; its generalized merge kind computes in the y type,
+// merge_genl.cuh:29-31): a value is widened when it meets x, products and sums are val_t throughout.
+template <int BLOCK, int IPT, bool VEC, bool WINDOW, int S, bool SEARCH, typename off_t, typename val_t, typename mat_t = val_t>
 __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
     int32_t n_rows, int32_t n_cols, int64_t nnz_begin, int64_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
-    const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
+    const mat_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
     int32_t* __restrict__ tile_row_g, int64_t* __restrict__ tile_nnz_g, int64_t tile_items,
     int32_t* __restrict__ carry_row, val_t* __restrict__ carry_val, int64_t n_tiles, int32_t tiles_per_super,
     int32_t window_cap, BandHint hint, val_t alpha, val_t beta) {
     constexpr int G = IPT / 4;
     using v4 = typename Vec4<val_t>::type;
+    using m4 = typename Vec4<mat_t>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window_cap values of x
     val_t* s_x = reinterpret_cast<val_t*>(s_dyn);
     __shared__ __attribute__((aligned(32))) val_t s_nz[BLOCK * IPT];   // products, index = nnz - (y0 & ~3)
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
 
     // registers holding the Aj/Ax groups of the tile about to be processed
     int4v c[G];
-    v4 a[G];
+    m4 a[G];
     // branch-free: addresses are clamped below the last whole 16-byte group of the arrays (hipcc
     // serialises loads it finds in branches); the few nonzeros at or past nnz_vec are redone below
     const int64_t nnz_vec = nnz & ~int64_t(3);
@@ -218,7 +233,7 @@ __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
             int64_t j = base + 4 * int64_t(tid + g * BLOCK);
             j = j < j_max ? j : j_max;
             c[g] = stream_load(reinterpret_cast<const int4v*>(Aj + j));
-            a[g] = stream_load(reinterpret_cast<const v4*>(Ax + j));
+            a[g] = stream_load(reinterpret_cast<const m4*>(Ax + j));
         }
     };
     if constexpr (VEC) issue(y0);
@@ -264,24 +279,26 @@ __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
         // (1) products a*x for the tile's nonzeros
         if constexpr (VEC) {
             if constexpr (WINDOW) {
+                // (this kernel is bound by instruction issue: the lookup is a clamp (v_min), an address and one
+                // compare per element; which elements are REAL nonzeros of the tile is only worked out in the rare
+                // branch where some column fell outside the window)
+                const unsigned len_m1 = unsigned(win.len > 0 ? win.len - 1 : 0);
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const int rel0 = 4 * (tid + g * BLOCK) - shift;   // tile-relative index of element 0
                     v4 p;
-                    bool need[4];
-                    bool any_need = false;
+                    bool any_out = false;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const unsigned rel = unsigned(c[g][e] - win.lo);
-                        const bool in = rel < unsigned(win.len);
-                        p[e] = SR::combine(a[g][e], win.s_x[in ? rel : 0u]);
-                        need[e] = !in && (rel0 + e >= 0) && (rel0 + e < tn);
-                        any_need |= need[e];
+                        any_out |= rel >= unsigned(win.len);
+                        p[e] = SR::combine(val_t(a[g][e]), win.s_x[min(rel, len_m1)]);
                     }
-                    if (any_need) {                      // rare: loaded and consumed inside the branch
+                    if (any_out) {                       // rare: loaded and consumed inside the branch
+                        const int rel0 = 4 * (tid + g * BLOCK) - shift;   // tile-relative index of element 0
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            if (need[e]) p[e] = SR::combine(a[g][e], x[c[g][e]]);
+                            const bool out = unsigned(c[g][e] - win.lo) >= unsigned(win.len);
+                            if (out && (rel0 + e >= 0) && (rel0 + e < tn)) p[e] = SR::combine(val_t(a[g][e]), x[c[g][e]]);
                         }
                     }
                     *reinterpret_cast<v4*>(&s_nz[4 * (tid + g * BLOCK)]) = p;
@@ -296,7 +313,7 @@ __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
                 for (int g = 0; g < G; ++g) {
                     v4 p;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) p[e] = SR::combine(a[g][e], xv[g][e]);
+                    for (int e = 0; e < 4; ++e) p[e] = SR::combine(val_t(a[g][e]), xv[g][e]);
                     *reinterpret_cast<v4*>(&s_nz[4 * (tid + g * BLOCK)]) = p;
                 }
             }
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
                 // wrong about once in 25 processes).
                 __syncthreads();
                 const int64_t k = (y0 > nnz_vec ? y0 : nnz_vec) + tid;
-                if (k < y1) s_nz[int(k - y0) + shift] = SR::combine(Ax[k], x[Aj[k]]);
+                if (k < y1) s_nz[int(k - y0) + shift] = SR::combine(val_t(Ax[k]), x[Aj[k]]);
             }
             // the next tile's stream goes in flight now and lands while this tile is walked
             if (t + 1 < last) issue(y1);
@@ -315,7 +332,7 @@ __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
             // Aj / Ax not 16-byte aligned (an offset view): 4-byte-per-lane form
             for (int i = tid; i < tn; i += BLOCK) {
                 const int32_t col = Aj[y0 + i];
-                s_nz[i] = SR::combine(Ax[y0 + i], window_gather<val_t>(win, x, col, true));
+                s_nz[i] = SR::combine(val_t(Ax[y0 + i]), window_gather<val_t>(win, x, col, true));
             }
         }
         // (2) row ends, relative to y0; the row still open at the tile end never ends here
@@ -504,8 +521,8 @@ void shape_merge(Plan& p) {
     snprintf(p.main_kernel, sizeof(p.main_kernel), "merge_tile_kernel");
 }
 
-template <typename off_t, typename val_t>
-int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s) {
+template <typename off_t, typename val_t, typename mat_t>
+int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_t* y, hipStream_t s) {
     if (p.n_rows == 0 || p.n_tiles == 0) return MI355_SPMV_OK;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
@@ -542,17 +559,17 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
     do {                                                                                                      \
         if constexpr (S_ == MI355_SEMIRING_PLUS_TIMES) {                                                      \
             if (wide) {                                                                                       \
-                hipLaunchKernelGGL((merge_tile_kernel<kWideBlock, 4, VEC_, WIN_, S_, false, off_t, val_t>), grid, dim3(kWideBlock), MI355_MERGE_ARGS); \
+                hipLaunchKernelGGL((merge_tile_kernel<kWideBlock, 4, VEC_, WIN_, S_, false, off_t, val_t, mat_t>), grid, dim3(kWideBlock), MI355_MERGE_ARGS); \
                 break;                                                                                        \
             }                                                                                                 \
         }                                                                                                     \
         if constexpr (VEC_) {                                                                                 \
             if (fused) {                                                                                      \
-                hipLaunchKernelGGL((merge_tile_kernel<kBlock, 8, VEC_, WIN_, S_, true, off_t, val_t>), grid, dim3(kBlock), MI355_MERGE_ARGS); \
+                hipLaunchKernelGGL((merge_tile_kernel<kBlock, 8, VEC_, WIN_, S_, true, off_t, val_t, mat_t>), grid, dim3(kBlock), MI355_MERGE_ARGS); \
                 break;                                                                                        \
             }                                                                                                 \
         }                                                                                                     \
-        hipLaunchKernelGGL((merge_tile_kernel<kBlock, 8, VEC_, WIN_, S_, false, off_t, val_t>), grid, dim3(kBlock), MI355_MERGE_ARGS); \
+        hipLaunchKernelGGL((merge_tile_kernel<kBlock, 8, VEC_, WIN_, S_, false, off_t, val_t, mat_t>), grid, dim3(kBlock), MI355_MERGE_ARGS); \
     } while (0)
 #define MI355_MERGE_SEMIRING(S_)                                                    \
     do {                                                                            \
@@ -571,6 +588,8 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
         case MI355_SEMIRING_PLUS_TIMES: MI355_MERGE_SEMIRING(MI355_SEMIRING_PLUS_TIMES); break;
         case MI355_SEMIRING_MIN_PLUS:   MI355_MERGE_SEMIRING(MI355_SEMIRING_MIN_PLUS); break;
         case MI355_SEMIRING_MAX_TIMES:  MI355_MERGE_SEMIRING(MI355_SEMIRING_MAX_TIMES); break;
+        case MI355_SEMIRING_MAX_PLUS:   MI355_MERGE_SEMIRING(MI355_SEMIRING_MAX_PLUS); break;
+        case MI355_SEMIRING_OR_AND:     MI355_MERGE_SEMIRING(MI355_SEMIRING_OR_AND); break;
         default:
             set_error("merge: unknown semiring %d", p.semiring);
             return MI355_SPMV_EINVAL;
@@ -581,9 +600,12 @@ int launch_merge(Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_
     return MI355_SPMV_OK;
 }
 
-template int launch_merge<int32_t, float>(Plan&, const int32_t*, const float*, const float*, float*, hipStream_t);
-template int launch_merge<int32_t, double>(Plan&, const int32_t*, const double*, const double*, double*, hipStream_t);
-template int launch_merge<int64_t, float>(Plan&, const int64_t*, const float*, const float*, float*, hipStream_t);
-template int launch_merge<int64_t, double>(Plan&, const int64_t*, const double*, const double*, double*, hipStream_t);
+template int launch_merge<int32_t, float, float>(Plan&, const int32_t*, const float*, const float*, float*, hipStream_t);
+template int launch_merge<int32_t, double, double>(Plan&, const int32_t*, const double*, const double*, double*, hipStream_t);
+template int launch_merge<int64_t, float, float>(Plan&, const int64_t*, const float*, const float*, float*, hipStream_t);
+template int launch_merge<int64_t, double, double>(Plan&, const int64_t*, const double*, const double*, double*, hipStream_t);
+// fp32 matrix under fp64 vectors (mi355_spmv_plan_create_typed)
+template int launch_merge<int32_t, double, float>(Plan&, const int32_t*, const float*, const double*, double*, hipStream_t);
+template int launch_merge<int64_t, double, float>(Plan&, const int64_t*, const float*, const double*, double*, hipStream_t);
 
 }  // namespace mi355

@@ -44,6 +44,8 @@ inline void check(int status, const char* what, const char* file, int line) {
 struct PlusTimes { static constexpr int id = MI355_SEMIRING_PLUS_TIMES; };   // the reference's MergeFunctor
 struct MinPlus   { static constexpr int id = MI355_SEMIRING_MIN_PLUS; };
 struct MaxTimes  { static constexpr int id = MI355_SEMIRING_MAX_TIMES; };
+struct MaxPlus   { static constexpr int id = MI355_SEMIRING_MAX_PLUS; };
+struct OrAnd     { static constexpr int id = MI355_SEMIRING_OR_AND; };     // booleans as 0.0 / 1.0
 
 template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,
           typename vec_y_value_t>
@@ -55,16 +57,24 @@ void run_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const offs
     static_assert(sizeof(offset_t) == 4 || sizeof(offset_t) == 8, "mi355 kinds: offset_t must be 32- or 64-bit");
     static_assert(std::is_integral<offset_t>::value && std::is_signed<offset_t>::value,
                   "mi355 kinds: offset_t must be a signed integer");
-    static_assert(std::is_same<mat_value_t, vec_x_value_t>::value && std::is_same<mat_value_t, vec_y_value_t>::value,
-                  "mi355 kinds: A, x and y share one value type (reference main.cu:17)");
-    static_assert(std::is_same<mat_value_t, float>::value || std::is_same<mat_value_t, double>::value,
-                  "mi355 kinds: value type is float or double");
+    // A, x and y share one value type (reference main.cu:17) — or, for the merge kinds, an fp32 matrix sits under
+    // fp64 vectors (the reference's template keeps the three apart, spmv.h:29-34; merge_genl.cuh:29-31 computes in
+    // the y type).  Anything else is not built: mi355_spmv_plan_create_typed returns ENOTSUP and the check aborts.
+    static_assert(std::is_same<vec_x_value_t, vec_y_value_t>::value, "mi355 kinds: x and y share one value type");
+    static_assert((std::is_same<mat_value_t, float>::value || std::is_same<mat_value_t, double>::value) &&
+                      (std::is_same<vec_x_value_t, float>::value || std::is_same<vec_x_value_t, double>::value),
+                  "mi355 kinds: value types are float or double");
+    static_assert(std::is_same<mat_value_t, vec_x_value_t>::value ||
+                      (std::is_same<mat_value_t, float>::value && std::is_same<vec_x_value_t, double>::value),
+                  "mi355 kinds: the only mixed combination is an fp32 matrix under fp64 vectors");
     const int off_type = sizeof(offset_t) == 8 ? MI355_OFF_I64 : MI355_OFF_I32;
-    const int val_type = std::is_same<mat_value_t, double>::value ? MI355_VAL_F64 : MI355_VAL_F32;
+    const int mat_type = std::is_same<mat_value_t, double>::value ? MI355_VAL_F64 : MI355_VAL_F32;
+    const int vec_type = std::is_same<vec_x_value_t, double>::value ? MI355_VAL_F64 : MI355_VAL_F32;
 
     mi355_spmv_plan* plan = nullptr;
-    MI355_CHECK(mi355_spmv_plan_create(&plan, kind, off_type, val_type, (int32_t)n_rows, (int32_t)n_cols,
-                                       (int64_t)nnz, Ap, reinterpret_cast<const int32_t*>(Aj), MI355_PLAN_DEFAULT));
+    MI355_CHECK(mi355_spmv_plan_create_typed(&plan, kind, off_type, mat_type, vec_type, vec_type, (int32_t)n_rows,
+                                             (int32_t)n_cols, (int64_t)nnz, Ap, reinterpret_cast<const int32_t*>(Aj),
+                                             MI355_PLAN_DEFAULT));
     if (semiring != MI355_SEMIRING_PLUS_TIMES) MI355_CHECK(mi355_spmv_plan_set_semiring(plan, semiring));
     Timer::kernel_start();
     MI355_CHECK(mi355_spmv_plan_execute(plan, Ax, x, y, /*stream=*/nullptr));
@@ -168,7 +178,7 @@ MI355_DEFINE_DIST_KIND(SpMV_hip_dist_merge, MI355_KIND_MERGE)
 MI355_DEFINE_DIST_KIND(SpMV_hip_dist_light, MI355_KIND_LIGHT)
 
 /// generalized merge-path SpMV (cf. SpMV_merge_based_generalized, merge_genl.cuh:41-79);
-/// functor_t is one of mi355_host::PlusTimes (default, the reference's MergeFunctor), MinPlus, MaxTimes
+/// functor_t is one of mi355_host::PlusTimes (default, the reference's MergeFunctor), MinPlus, MaxTimes, MaxPlus, OrAnd
 template <typename functor_t = ::mi355_host::PlusTimes, typename index_t, typename offset_t,
           typename mat_value_t, typename vec_x_value_t, typename vec_y_value_t>
 void SpMV_hip_merge_generalized(index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap,

@@ -108,6 +108,55 @@ static int run_combo(const char* combo, int n_rows, int n_cols, int max_len) {
     return failures;
 }
 
+// fp32 matrix under fp64 vectors through the template boundary: SpMV<int, int, float, double, double>("hip_merge", ...)
+static int run_mixed() {
+    const int n_rows = 4001, n_cols = 3000;
+    unsigned long long seed = 777;
+    std::vector<int> Ap(n_rows + 1, 0), Aj;
+    std::vector<float> Ax;
+    for (int r = 0; r < n_rows; ++r) {
+        const int len = (r == 1000) ? 9000 : int(lcg(seed) % 20u);
+        for (int k = 0; k < len; ++k) {
+            Aj.push_back(int(lcg(seed) % (unsigned)n_cols));
+            Ax.push_back(float(double(lcg(seed) % 2001) / 1000.0 - 1.0));
+        }
+        Ap[r + 1] = int(Aj.size());
+    }
+    const int nnz = int(Aj.size());
+    std::vector<double> x(n_cols), ref(n_rows), mag(n_rows), y(n_rows);
+    for (int c = 0; c < n_cols; ++c) x[c] = double(lcg(seed) % 200001) / 100000.0 - 1.0;
+    for (int r = 0; r < n_rows; ++r) {
+        double s = 0, a = 0;
+        for (int k = Ap[r]; k < Ap[r + 1]; ++k) { const double p = double(Ax[k]) * x[Aj[k]]; s += p; a += std::fabs(p); }
+        ref[r] = s; mag[r] = a;
+    }
+    int* dAp; int* dAj; float* dAx; double *dX, *dY;
+    HIP_OK(hipMalloc((void**)&dAp, (n_rows + 1) * sizeof(int)));
+    HIP_OK(hipMalloc((void**)&dAj, (size_t(nnz) + 4) * sizeof(int)));
+    HIP_OK(hipMalloc((void**)&dAx, (size_t(nnz) + 4) * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&dX, n_cols * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&dY, n_rows * sizeof(double)));
+    HIP_OK(hipMemcpy(dAp, Ap.data(), (n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dAj, Aj.data(), size_t(nnz) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dAx, Ax.data(), size_t(nnz) * sizeof(float), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dX, x.data(), n_cols * sizeof(double), hipMemcpyHostToDevice));
+    int failures = 0;
+    for (const char* label : {"hip_merge", "hip_merge_genl"}) {
+        std::vector<double> poison(n_rows, std::numeric_limits<double>::quiet_NaN());
+        HIP_OK(hipMemcpy(dY, poison.data(), n_rows * sizeof(double), hipMemcpyHostToDevice));
+        if (std::strcmp(label, "hip_merge") == 0) SpMV_hip_merge<int, int, float, double, double>(n_rows, n_cols, nnz, dAp, dAj, dAx, dX, dY);
+        else SpMV_hip_merge_generalized<mi355_host::PlusTimes, int, int, float, double, double>(n_rows, n_cols, nnz, dAp, dAj, dAx, dX, dY);
+        HIP_OK(hipMemcpy(y.data(), dY, n_rows * sizeof(double), hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int r = 0; r < n_rows; ++r)
+            if (!(std::fabs(y[r] - ref[r]) <= (double(Ap[r + 1] - Ap[r]) + 2) * std::ldexp(1.0, -53) * mag[r])) ++bad;
+        std::printf("[%-14s] f32mat_f64vec rows=%d nnz=%d bad_rows=%d\n", label, n_rows, nnz, bad);
+        failures += bad ? 1 : 0;
+    }
+    HIP_OK(hipFree(dAp)); HIP_OK(hipFree(dAj)); HIP_OK(hipFree(dAx)); HIP_OK(hipFree(dX)); HIP_OK(hipFree(dY));
+    return failures;
+}
+
 int main(int argc, char** argv) {
     HIP_OK(hipSetDevice(0));  // USED_DEVICE 0 (common.cuh:8)
     if (argc > 1 && std::strcmp(argv[1], "--bad-label") == 0) {
@@ -122,6 +171,7 @@ int main(int argc, char** argv) {
     failures += run_combo<int, double>("i32_f64", 3001, 2500, 24);
     failures += run_combo<long long, float>("i64_f32", 3001, 2500, 24);
     failures += run_combo<long long, double>("i64_f64", 777, 1, 3);  // n_cols == 1
+    failures += run_mixed();
     std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
     return failures ? 1 : 0;
 }

@@ -31,7 +31,8 @@ def test_cpp_boundary_all_labels_and_types():
     assert "ALL PASSED" in r.stdout
     for label in ("hip_vector", "hip_merge", "hip_light", "hip_merge_genl", "hip_dist_vector", "hip_dist_merge",
                   "hip_dist_light"):
-        assert r.stdout.count("[%-14s]" % label) == 4
+        assert r.stdout.count("[%-14s]" % label) == (5 if label in ("hip_merge", "hip_merge_genl") else 4)
+    assert r.stdout.count("f32mat_f64vec") == 2
 
 
 def test_cpp_boundary_unknown_label_exits_like_the_reference():

@@ -522,7 +522,7 @@ def test_more_than_2_to_31_nonzeros_with_64bit_offsets(sp, kind):
 
 # ---- generalized merge-path SpMV ---------------------------------------------
 
-@pytest.mark.parametrize("semiring", ["plus_times", "min_plus", "max_times"])
+@pytest.mark.parametrize("semiring", ["plus_times", "min_plus", "max_times", "max_plus", "or_and"])
 @pytest.mark.parametrize("off,val", COMBOS)
 def test_generalized_merge_semirings(sp, oracle, semiring, off, val):
     """min and max never round and a+x / a*x round once, so (min,+) and (max,*) must equal the
@@ -531,6 +531,9 @@ def test_generalized_merge_semirings(sp, oracle, semiring, off, val):
     rng = np.random.RandomState(77)
     Ap, Aj, Ax = random_csr(rng, 30011, 2000, 25, NP[off], NP[val], long_row=70000)
     x = (rng.rand(2000) * 2 - 1).astype(NP[val])
+    if semiring == "or_and":                                  # booleans as 0.0 / 1.0, about one in eight set
+        Ax = (rng.rand(Ax.size) < 0.5).astype(NP[val])
+        x = (rng.rand(2000) < 0.25).astype(NP[val])
     d = lambda a: torch.from_numpy(a).to(DEV)
     y = torch.full((30011,), float("nan"), dtype=d(Ax).dtype, device=DEV)
     sp.spmv_genl(semiring, 30011, 2000, int(Ap[-1]), d(Ap), d(Aj), d(Ax), d(x), y)
@@ -656,3 +659,41 @@ def test_randomized_structures(sp, oracle, structure, off, val):
         for kind in KINDS:
             y = gpu_spmv(sp, kind, n_cols, Ap, Aj, Ax, x, plan=(trial % 2 == 0))
             assert_parity(oracle, Ap, Aj, Ax, x, y, exact=integer)
+
+
+# ---- separate matrix / vector value types (reference include/spmv.h:29-34) -------------------------------
+
+@pytest.mark.parametrize("off", ["i32", "i64"])
+def test_fp32_matrix_under_fp64_vectors_merge(sp, oracle, off):
+    """mi355_spmv_plan_create_typed: matrix stored in fp32, x / y and all arithmetic fp64 (merge kind).  The
+    result must sit inside the fp64 bound around the serial fp64 sum of the WIDENED matrix — i.e. no fp32
+    rounding anywhere — for ragged rows, a window-friendly band and a hub row; other combinations are refused."""
+    rng = np.random.RandomState(71)
+    cases = [random_csr(rng, 20011, 5000, 12, NP[off], np.float32, long_row=30000)]
+    m = sp.synth.banded_fixed(200_000, 32, 700, seed=8, device="cpu", off_dtype=torch.int64 if off == "i64" else torch.int32)
+    cases.append(m.numpy())
+    for Ap, Aj, Ax in cases:
+        n_rows, n_cols = len(Ap) - 1, int(Aj.max()) + 1
+        x = (rng.rand(n_cols) * 2 - 1)
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+        dAp, dAj, dAx, dx = d(Ap), d(Aj), d(Ax), d(x)
+        y = torch.full((n_rows,), float("nan"), dtype=torch.float64, device=DEV)
+        sp.spmv_mixed(n_rows, n_cols, int(Ap[-1]), dAp, dAj, dAx, dx, y)
+        y64, bound = parity_bound(oracle, Ap, Aj, Ax.astype(np.float64), x)
+        err = np.abs(y.cpu().numpy() - y64)
+        assert not np.isnan(err).any() and np.all(err <= bound), int((err > bound).sum())
+        # the same through a plan, with alpha / beta
+        p = sp.Plan("merge", n_rows, n_cols, int(Ap[-1]), dAp, dAj, torch.float64, mat_dtype=torch.float32)
+        p.set_alpha_beta(-0.5, 0.25)
+        y0 = rng.rand(n_rows)
+        y2 = d(y0)
+        p.execute(dAx, dx, y2)
+        torch.cuda.synchronize()
+        p.destroy()
+        assert np.all(np.abs(y2.cpu().numpy() - (-0.5 * y64 + 0.25 * y0)) <= 0.5 * bound + 1e-300)
+    dAp, dAj = d(cases[0][0]), d(cases[0][1])
+    for kind in ("vector", "light"):
+        with pytest.raises(RuntimeError, match="not supported"):
+            sp.Plan(kind, 20011, 5000, int(cases[0][0][-1]), dAp, dAj, torch.float64, mat_dtype=torch.float32)
+    with pytest.raises(RuntimeError, match="not supported"):
+        sp.Plan("merge", 20011, 5000, int(cases[0][0][-1]), dAp, dAj, torch.float32, mat_dtype=torch.float64)

@@ -181,11 +181,11 @@ def test_merge_tile_coords_properties(oracle):
 
 # ---- generalized (semiring) SpMV: cpu_navie.hpp:20-34 -------------------------------------------
 
-@pytest.mark.parametrize("semiring", [0, 1, 2])
+@pytest.mark.parametrize("semiring", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("off,val", COMBOS)
 def test_generalized_serial_matches_reference_build(oracle, ref, semiring, off, val):
     """The reference's own SpMV_genl_cpu_navie<functor_t>, instantiated in oracle/ref_driver.cpp with
-    (+,*), (min,+) and (max,*), against the restatement — bit for bit, empty rows included."""
+    (+,*), (min,+), (max,*), (max,+) and (or,and), against the restatement — bit for bit, empty rows included."""
     rng = np.random.RandomState(40 + semiring)
     Ap, Aj, Ax = random_csr(rng, 500, 200, 30, NP[off], NP[val], long_row=900)
     x = (rng.rand(200) * 2 - 1).astype(NP[val])
@@ -194,7 +194,7 @@ def test_generalized_serial_matches_reference_build(oracle, ref, semiring, off, 
     assert np.array_equal(got, want)
     empty = np.diff(Ap.astype(np.int64)) == 0
     assert empty.any()
-    ident = {0: 0.0, 1: np.inf, 2: -np.inf}[semiring]
+    ident = {0: 0.0, 1: np.inf, 2: -np.inf, 3: -np.inf, 4: 0.0}[semiring]
     assert np.all(got[empty] == ident)                       # an empty row yields initialize()
     if semiring == 0:
         assert np.array_equal(got, oracle.spmv_serial(Ap, Aj, Ax, x))
@@ -209,3 +209,16 @@ def test_ref64_threads_do_not_change_values(oracle):
     for t in (2, 7, 16):
         b = oracle.spmv_ref64(Ap, Aj, Ax, x, t)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("off", [np.int32, np.int64])
+def test_mixed_types_restatement_equals_the_reference_template(oracle, ref, off):
+    """fp32 matrix under fp64 vectors: the oracle's loop against the reference's own SpMV_cpu_navie
+    instantiated <int, off, float, double, double> (include/spmv.h:29-34 keeps the three value types apart),
+    bit for bit; and against the fp64 loop on the widened matrix (a float widens exactly)."""
+    rng = np.random.RandomState(31)
+    Ap, Aj, Ax = random_csr(rng, 3001, 800, 30, off, np.float32, long_row=5000)
+    x = (rng.rand(800) * 2 - 1).astype(np.float64)
+    y = oracle.spmv_serial_mixed(Ap, Aj, Ax, x)
+    assert np.array_equal(y, ref.spmv_cpu_mixed(800, Ap, Aj, Ax, x))
+    assert np.array_equal(y, oracle.spmv_serial(Ap, Aj, Ax.astype(np.float64), x))
