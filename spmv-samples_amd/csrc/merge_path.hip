@@ -493,7 +493,7 @@ void shape_merge(Plan& p) {
     // tuning knobs: MI355_MERGE_TPS = tiles per run (and MI355_SPMV_WINDOW = 0|1, analyze.hip)
     // 256 threads x 8 items or (MI355_MERGE_BLOCK=512) 512 threads x 4 items: the same 2 044-item tiles
     p.block_threads = p.knob.merge_block == kWideBlock ? kWideBlock : kBlock;
-    const int ipt = p.block_threads == kWideBlock ? 4 : 8;   // (16 measured no better)
+    const int ipt = p.block_threads == kWideBlock ? 4 : 8;   // (16: S32-band 251 vs 259 us, web-Google stand-in 52.4 vs 46.4: not kept)
     p.lanes_per_row = 0;
     p.elems_per_lane = ipt;            // reported as items per thread for this kind
     p.tile_items = int64_t(p.block_threads) * ipt - 4;
