@@ -138,6 +138,7 @@ class Runner:
 
     def __init__(self, sp, kind, m, cuts, rank, world, sub_blocks, unique_id, flags, use_dist):
         self.kind, self.m, self.use_dist = kind, m, use_dist
+        self.blocks, self.exchange = None, "none (single GPU)"
         if not use_dist:
             self.plan = sp.Plan(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype, flags)
             self.Ax, self.n_rows_global, self.n_rows_local, self.nnz_local = m.Ax, m.n_rows, m.n_rows, m.nnz
@@ -155,17 +156,61 @@ class Runner:
         self.Ax = Ax_l
         self.n_rows_global, self.n_rows_local = rows[-1], r1 - r0
         self.nnz_local = nnzs[(rank + 1) * sub_blocks] - nnzs[rank * sub_blocks]
-        self.plan = sp.DistPlan.rank(kind, rank, world, unique_id, sub_blocks, rows, chunks, nnzs, shape, m.n_cols,
-                                     r1 - r0, int(Ap_l[-1].item()), Ap_l, Aj_l, m.Ax.dtype, flags)
+        self.exchange = "mi355_spmv_dist_* (grouped in-place ncclBroadcast per sub-block on a communication stream)"
+        self.blocks = None
+        err = ""
+        try:
+            self.plan = sp.DistPlan.rank(kind, rank, world, unique_id, sub_blocks, rows, chunks, nnzs, shape, m.n_cols,
+                                         r1 - r0, int(Ap_l[-1].item()), Ap_l, Aj_l, m.Ax.dtype, flags)
+            ok = 1
+        except RuntimeError as e:              # (never seen: the N > 1 leg cannot be rehearsed on the one-GPU test pool)
+            self.plan, ok, err = None, 0, str(e)
+        if os.environ.get("MI355_BENCH_FORCE_FALLBACK"):     # (rehearsal of the safety net on one GPU)
+            ok, err = 0, "forced by MI355_BENCH_FORCE_FALLBACK"
+        if world > 1:
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            # Safety net so that a scaling run still measures something: the same row blocks through the C ABI's
+            # block plans, the exchange through torch.distributed's RCCL group instead of the library's own.
+            if self.plan is not None:
+                self.plan.destroy()
+            sys.stderr.write("bench.py: mi355_spmv_dist_create_rank failed (%s); exchanging y through torch.distributed\n" % err)
+            self.exchange = "FALLBACK torch.distributed over RCCL (the library's own communicator failed: %s)" % (err or "on another rank")
+            self.pg = dist.new_group(backend="nccl")
+            self.rank_cuts = [rows[r * sub_blocks] for r in range(world)] + [rows[-1]]
+            self.blocks = []
+            for b in range(rank * sub_blocks, (rank + 1) * sub_blocks):
+                a, j, v, _ = sp.dist.block_view(Ap_l, Aj_l, Ax_l, rows[b] - r0, rows[b + 1] - r0)
+                if rows[b + 1] == rows[b]:
+                    continue
+                cb = chunks[b] if chunks is not None else 0
+                nc = (chunks[b + 1] - chunks[b]) if chunks is not None else 0
+                pl = sp.Plan.block(kind, shape, rows[b], cb, nc, nnzs[b], rows[b + 1] - rows[b], m.n_cols,
+                                   int(a[-1].item()), a, j, m.Ax.dtype, flags)
+                self.blocks.append((pl, v, rows[b], rows[b + 1]))
+            self.plan = self.blocks[0][0]
+            self.sp, self.rank = sp, rank
 
     def execute(self, x, y):
-        self.plan.execute(self.Ax, x, y)
+        if self.blocks is None:
+            self.plan.execute(self.Ax, x, y)
+            return
+        for pl, v, b0, b1 in self.blocks:
+            pl.execute(v, x, y[b0:b1])
+        lo, hi = self.rank_cuts[self.rank], self.rank_cuts[self.rank + 1]
+        self.sp.dist.allgatherv(y[lo:hi], y, self.rank_cuts, group=self.pg)
 
     def info(self):
         return self.plan.info()        # (multi-GPU object: its first block's launch shape)
 
     def destroy(self):
-        self.plan.destroy()
+        if self.blocks is None:
+            self.plan.destroy()
+        else:
+            for pl, _, _, _ in self.blocks:
+                pl.destroy()
 
 
 _FLUSH = {"buf": None}
@@ -272,6 +317,11 @@ def main():
         spawn_ranks(args.gpus)                                          # (does not return)
     if launched:
         args.gpus = world
+    # stdout carries exactly ONE line, the JSON: gloo ("[Gloo] Rank 0 is connected ...") and RCCL (its version banner)
+    # print to fd 1 when a process group / communicator comes up, so fd 1 points at stderr until that line is due
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -285,8 +335,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         if world > 1:
-            # RCCL prints a version banner on stdout when a communicator comes up; stdout is reserved for
-            # the one JSON line, so fd 1 points at stderr while communicators are made (Runner, below)
             box = [sp.DistPlan.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             unique_id = box[0]
@@ -297,10 +345,7 @@ def main():
     x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, dev)  # same seed on every rank: replicated x
     flags = sp.capi.PLAN_REUSE_STRUCTURE if args.reuse_structure else 0
     kinds = KINDS if args.kind == "auto" or args.all_kinds else (args.kind,)
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)
-    try:
+    if True:
         # (a fresh 128-byte id per communicator: one per kind when several kinds are timed)
         runs = {}
         for k in kinds:
@@ -320,9 +365,6 @@ def main():
         for k, r in runs.items():
             _, ms = time_steps(r, x, y, use_dist, max(args.warmup, 30))
             probe[k] = float(np.mean(ms))
-    finally:
-        os.dup2(saved, 1)
-        os.close(saved)
     kind = args.kind
     if kind == "auto":
         best = torch.tensor([probe[k] for k in KINDS], dtype=torch.float64)
@@ -376,8 +418,7 @@ def main():
                        "kernels_per_step": info["n_kernels"], "x_window_elems": info["window_elems"],
                        "x_window_segments": info["window_segments"], "reuse_structure": bool(args.reuse_structure),
                        "knobs": info["knobs"],
-                       "parallelism": ("%d GPU x %d row blocks, x replicated, allgatherv(y) = grouped in-place ncclBroadcast "
-                                       "per sub-block on a communication stream (mi355_spmv_dist_*)" % (world, sub_blocks))
+                       "parallelism": ("%d GPU x %d row blocks, x replicated, allgatherv(y): %s" % (world, sub_blocks, run.exchange))
                                       if use_dist else "single GPU"},
             "achieved_hbm_gbps": achieved,
             # this GPU's step by HIP events: the SpMV alone on one GPU; SpMV + exchange when N > 1
@@ -398,7 +439,8 @@ def main():
             out["one_shot_ms"] = one_shot_ms(sp, kind, m, x, y)
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, x, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     for r in runs.values():
         r.destroy()
     if use_dist:
