@@ -250,6 +250,7 @@ int allow_dynamic_lds(const void* kernel, size_t bytes) {
 // 512 threads; four of 256 when the body keeps 2 rows per vector in flight (fp64; fp32 with 16+ lanes per row),
 // three with 4 rows (fp32, up to 8 lanes per row, and the per-chunk-width kernels of weight-cut plans).
 int workgroups_per_cu_by_registers(const Plan& p) {
+    if (p.block_threads == kHugeBlock) return 1;
     if (p.block_threads == kWideBlock) return 2;
     if (p.balanced) return p.val_type == MI355_VAL_F64 ? 4 : 3;
     return (p.val_type == MI355_VAL_F64 || p.lanes_per_row >= 16) ? 4 : 3;
@@ -556,7 +557,7 @@ static int window_budget(const Plan& p, int block_threads, int64_t rows) {
 // often per row and 2 x 8 waves sit on a CU instead of 3 x 4 (LDS-bound either way): 190 -> 178 us on the
 // S32-band target (LIGHT: 199 -> 195 us once its kernel is held to 128 VGPRs; at 151 only one such workgroup
 // fits a CU and it lost, 237 us).
-void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
+void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide, bool allow_huge) {
     if (p.val_type == MI355_VAL_F32 && p.lanes_per_row >= 16 && R > 2) R = 2;   // (the kernels' rule: launch_*_window, wide_r)
     auto shape = [&](int block_threads, int64_t nnz_per_chunk) {
         p.block_threads = block_threads;
@@ -638,6 +639,28 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide) {
             p.window_bytes = int(val_bytes * (band + rows + 8));
             p.window_elems = pick_window_elems(p, rows);
             if (!(p.window_elems > 0 && p.n_seg < 2 && p.window_from_band)) p = saved;   // (several bands etc.: keep the 256-thread plan)
+        }
+    }
+    // Still no window: the band is wider than two workgroups per CU can hold (round 1: every kind fell to the
+    // plain-gather rate, 1.6-2.5 TB/s, once the band passed ~17 K columns in fp32 / ~9 K in fp64).  ONE workgroup
+    // of 1 024 threads per CU can take ~155 of the CU's 160 KB: twice the band.  Its prologue is not hidden by a
+    // neighbour, so this is only worth it where the alternative is the plain gather.
+    if (allow_huge && !force && p.probe_ok && p.window_elems == 0 && p.knob.window < 0 && p.knob.rows_per_chunk <= 0) {
+        const int64_t val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
+        const int64_t band = p.band_hi - p.band_lo + 1;
+        const int64_t pass = int64_t(kHugeBlock / p.lanes_per_row) * R;
+        // val (band + rows + 8) + 4 (rows + 1) + val rows + rows / 8 <= 155 KB
+        int64_t rows = (155 * 1024 - val_bytes * (band + 8) - 4) * 8 / (8 * (2 * val_bytes + 4) + 1);
+        rows = rows / pass * pass;
+        if (rows > kMaxChunkRows) rows = kMaxChunkRows / pass * pass;
+        const int64_t n_chunks = rows > 0 ? (p.n_rows + rows - 1) / rows : 0;
+        if (band > 0 && rows >= pass && rows >= 512 && n_chunks >= int64_t(kCus) * 2) {
+            const Plan saved = p;
+            p.block_threads = kHugeBlock;
+            p.rows_per_chunk = rows;
+            p.window_bytes = int(val_bytes * (band + rows + 8));
+            p.window_elems = pick_window_elems(p, rows);
+            if (!(p.window_elems > 0 && p.n_seg < 2 && p.window_from_band)) p = saved;
         }
     }
 }

@@ -17,6 +17,7 @@ constexpr int kMaxGiantRows = 256;    // giant rows a plan handles (more: they s
 constexpr int64_t kGiantRow = 65536;   // a row beyond this many nonzeros is cut into slices of kGiantSlice
 constexpr int64_t kGiantSlice = 32768;
 constexpr int kWideBlock = 512;      // VECTOR / LIGHT on big uniform matrices: 8 waves, chunks twice as long
+constexpr int kHugeBlock = 1024;     // VECTOR, band too wide for two workgroups per CU: ONE 16-wave workgroup with ~150 KB of LDS
 constexpr int kXcds = 8;             // XCDs per MI355X, each with a private L2
 constexpr int kCus = 256;            // compute units per MI355X
 
@@ -160,7 +161,7 @@ int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x
 int probe_structure(Plan& p);
 int pick_window_elems(Plan& p, int64_t rows_per_workgroup);
 int64_t segment_rows_fit(const Plan& p);
-void shape_chunks(Plan& p, int rows_in_flight, int64_t chunk_div, bool allow_wide);   // VECTOR / LIGHT: block size, chunk, window
+void shape_chunks(Plan& p, int rows_in_flight, int64_t chunk_div, bool allow_wide, bool allow_huge = false);   // VECTOR / LIGHT: block size, chunk, window
 int workgroups_per_cu_by_registers(const Plan& p);   // VECTOR / LIGHT: what the kernels' launch bounds allow
 int long_steps_for(const Plan& p);   // steps of its vector after which a row is left to the long-row pass
 int decide_balance(Plan& p);       // VECTOR / LIGHT, after shape_*: uniform or nnz-balanced chunks

@@ -30,7 +30,7 @@ namespace mi355 {
 // there — cant stand-in: 14.7 -> 19-21 us when its body went from 127 to 139 VGPRs.)  The kernel does not depend on the width
 // of the row offsets: a chunk is walked with 32-bit offsets relative to its own first nonzero (xwindow.hpp).
 template <int BLOCK, int T, int R, int NSEG, bool ADAPT, typename val_t>
-__global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock || R == 2 ? 4 : 3)) void csr_vector_window_kernel(
+__global__ __launch_bounds__(BLOCK, (BLOCK >= kWideBlock || R == 2 ? 4 : 3)) void csr_vector_window_kernel(
     int32_t n_rows, int32_t n_cols, int64_t nnz, const ApView Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, ChunkMap cmap,
     int32_t window_cap, BandHint hint, SegmentPlan segs, val_t alpha, val_t beta) {
@@ -111,7 +111,7 @@ void shape_vector(Plan& p) {
         const int t = p.knob.lanes;
         if (t == 2 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64) p.lanes_per_row = t;
     }
-    shape_chunks(p, R, 1, true);   // (analyze.hip)
+    shape_chunks(p, R, 1, true, true);   // (analyze.hip)
     p.grid_blocks = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
     if (p.grid_blocks < 1) p.grid_blocks = 1;
     p.n_tiles = p.grid_blocks;
@@ -141,10 +141,10 @@ void block_grid_vector(Plan& p) {
 template <int BLOCK, typename val_t>
 static int launch_vector_window(const Plan& p, const ApView Ap, const val_t* Ax, const val_t* x, val_t* y,
                                 hipStream_t s) {
-    if constexpr (BLOCK == kWideBlock) {
-        // a 512-thread plan is only ever shaped around a window of x; without one (a forced knob) the 256-thread
-        // kernel walks the same chunks (any workgroup size walks any chunk)
-        if (p.window_elems <= 0) return launch_vector_window<kBlock, val_t>(p, Ap, Ax, x, y, s);
+    if constexpr (BLOCK >= kWideBlock) {
+        // a 512- / 1 024-thread plan is only ever shaped around ONE window of x; without it (a forced knob) the
+        // 256-thread kernel walks the same chunks (any workgroup size walks any chunk)
+        if (p.window_elems <= 0 || p.n_seg >= 2) return launch_vector_window<kBlock, val_t>(p, Ap, Ax, x, y, s);
     }
     constexpr int R = rows_in_flight<val_t>();
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
@@ -241,8 +241,9 @@ int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* 
     const bool force_plain = p.knob.plain != 0 && !p.is_block;   // tuning / tests (a block keeps the whole plan's order)
     if (aligned && p.nnz >= 4 && !force_plain) {
         const ApView view{Ap, sizeof(off_t) == 8 ? 1 : 0};
-        return p.block_threads == kWideBlock ? launch_vector_window<kWideBlock, val_t>(p, view, Ax, x, y, s)
-                                             : launch_vector_window<kBlock, val_t>(p, view, Ax, x, y, s);
+        return p.block_threads == kHugeBlock   ? launch_vector_window<kHugeBlock, val_t>(p, view, Ax, x, y, s)
+               : p.block_threads == kWideBlock ? launch_vector_window<kWideBlock, val_t>(p, view, Ax, x, y, s)
+                                               : launch_vector_window<kBlock, val_t>(p, view, Ax, x, y, s);
     }
     return launch_vector_plain<off_t, val_t>(p, Ap, Ax, x, y, s);
 }

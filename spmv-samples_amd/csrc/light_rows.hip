@@ -90,7 +90,7 @@ __device__ __forceinline__ void light_leave(unsigned long long* __restrict__ cou
 // per CU need 3 waves per SIMD, <= 168 VGPRs.)  Like the CSR-vector kernel this one does not depend on the
 // width of the row offsets: a chunk is walked with 32-bit offsets relative to its first nonzero.
 template <int BLOCK, int T, int R, int NSEG, bool ADAPT, typename val_t>
-__global__ __launch_bounds__(BLOCK, (BLOCK == kWideBlock || R == 2 ? 4 : 3)) void light_rows_window_kernel(
+__global__ __launch_bounds__(BLOCK, (BLOCK >= kWideBlock || R == 2 ? 4 : 3)) void light_rows_window_kernel(
     int32_t n_rows, int32_t n_cols, int64_t nnz, const ApView Ap, const int32_t* __restrict__ Aj_arg,
     const val_t* __restrict__ Ax_arg, const val_t* __restrict__ x_arg, val_t* __restrict__ y_arg,
     unsigned long long* __restrict__ counters, ChunkMap cmap, int32_t window_cap, BandHint hint,
@@ -322,7 +322,7 @@ void shape_light(Plan& p) {
     const int div = p.knob.light_chunk_div;
     // chunks: the static kind's size (halving them cost 6 % on the S32-band target: the
     // window of x is staged per chunk), never below one pass of the workgroup
-    shape_chunks(p, R, div > 0 ? div : 1, true);
+    shape_chunks(p, R, div > 0 ? div : 1, true, true);
     p.n_tiles = (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk;
     p.grid_blocks = light_grid(p, p.n_tiles, light_resident(p, p.rows_per_chunk));
     p.light_dequeue_once = light_dequeue_once(p, p.n_tiles, light_resident(p, p.rows_per_chunk));
@@ -354,9 +354,9 @@ void block_grid_light(Plan& p) {
 template <int BLOCK, typename val_t>
 static int launch_light_window(const Plan& p, const ApView Ap, const val_t* Ax, const val_t* x, val_t* y,
                                hipStream_t s) {
-    if constexpr (BLOCK == kWideBlock) {
-        // (see launch_vector_window: no 512-thread kernel without a window of x)
-        if (p.window_elems <= 0) return launch_light_window<kBlock, val_t>(p, Ap, Ax, x, y, s);
+    if constexpr (BLOCK >= kWideBlock) {
+        // (see launch_vector_window: no 512- / 1 024-thread kernel without ONE window of x)
+        if (p.window_elems <= 0 || p.n_seg >= 2) return launch_light_window<kBlock, val_t>(p, Ap, Ax, x, y, s);
     }
     constexpr int R = light_rows_in_flight<val_t>();
     const BandHint hint{p.band_lo, p.band_hi, p.window_from_band};
@@ -450,8 +450,9 @@ int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
     if (aligned && p.nnz >= 4) {
         const ApView view{Ap, sizeof(off_t) == 8 ? 1 : 0};
-        return p.block_threads == kWideBlock ? launch_light_window<kWideBlock, val_t>(p, view, Ax, x, y, s)
-                                             : launch_light_window<kBlock, val_t>(p, view, Ax, x, y, s);
+        return p.block_threads == kHugeBlock   ? launch_light_window<kHugeBlock, val_t>(p, view, Ax, x, y, s)
+               : p.block_threads == kWideBlock ? launch_light_window<kWideBlock, val_t>(p, view, Ax, x, y, s)
+                                               : launch_light_window<kBlock, val_t>(p, view, Ax, x, y, s);
     }
     return launch_light_plain<off_t, val_t>(p, Ap, Ax, x, y, s);
 }

@@ -413,6 +413,33 @@ def test_weight_cut_chunks_with_a_band_window_in_fp64_i64(sp, oracle, kind):
 
 
 @pytest.mark.parametrize("kind", ["vector", "light"])
+@pytest.mark.parametrize("val", ["f32", "f64"])
+def test_band_too_wide_for_two_workgroups_takes_one_of_1024_threads(sp, oracle, val, kind):
+    """A band of 32 769 columns in fp32 (16 385 in fp64) is more than two workgroups per CU can hold in LDS; the row-based
+    kinds then run ONE 1 024-thread workgroup per CU with ~150 KB (round 1: plain gathers at 1.7 TB/s).  Every row
+    against the oracle bound; a matrix too small to fill the chip that way keeps the 256-thread plan."""
+    hw = 16384 if val == "f32" else 8192
+    n = 1_500_000
+    dt = torch.float32 if val == "f32" else torch.float64
+    m = sp.synth.banded_fixed(n, 32, hw, seed=4, device=DEV, val_dtype=dt)
+    x = sp.synth.dense_vector(m.n_cols, dt, 10, DEV)
+    p = sp.Plan(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, dt)
+    info = p.info()
+    if not any(k.startswith("MI355_SPMV_") for k in os.environ if k != "MI355_SPMV_LIB"):   # (no forced code path)
+        assert info["block_threads"] == 1024 and info["window_elems"] * m.Ax.element_size() > 100 * 1024, info
+    y = torch.full((n,), float("nan"), dtype=dt, device=DEV)
+    p.execute(m.Ax, x, y)
+    torch.cuda.synchronize()
+    p.destroy()
+    Ap, Aj, Ax = m.numpy()
+    assert_parity(oracle, Ap, Aj, Ax, x.cpu().numpy(), y.cpu().numpy())
+    small = sp.synth.banded_fixed(100_000, 32, hw, seed=4, device=DEV, val_dtype=dt)
+    p = sp.Plan(kind, small.n_rows, small.n_cols, small.nnz, small.Ap, small.Aj, dt)
+    assert p.info()["block_threads"] != 1024 or "MI355_SPMV_BLOCK" in os.environ
+    p.destroy()
+
+
+@pytest.mark.parametrize("kind", ["vector", "light"])
 def test_wide_band_fp64_takes_more_than_64_kb_of_lds(sp, oracle, kind):
     """The S32-band shape in fp64 (band of 8 193 columns = 64 KB of doubles): the window only fits when the
     workgroup takes more than the default 64 KB of LDS (two 512-thread workgroups of ~78 KB per CU).  Every
