@@ -311,6 +311,21 @@ int decide_balance(Plan& p) {
     if (p.n_chunks < 1) p.n_chunks = 1;
     p.rows_cap = int(2 * r0 + 4);              // Q / k rows, + 3 for the round-down of the boundaries
     p.balanced = true;
+    // Whole rounds (as shape_chunks does for equal-row chunks): 862 chunks on 768 workgroup slots are two rounds of
+    // full-size chunks, the second one an eighth full; cut the same weight into 2 x 768 smaller chunks instead.
+    // Only ever makes chunks smaller, so rows_cap holds.
+    if (p.knob.rows_per_chunk <= 0) {
+        const int64_t slots = int64_t(kCus) * workgroups_per_cu_by_registers(p);
+        const int64_t rounds = (p.n_chunks + slots - 1) / slots;
+        if (rounds <= 4 && p.n_chunks > slots / 2 && p.n_chunks % slots != 0) {
+            int64_t q = (weight + rounds * slots - 1) / (rounds * slots);
+            if (q < 8 * p.bal_k) q = 8 * p.bal_k;
+            if (q < p.bal_q) {
+                p.bal_q = q;
+                p.n_chunks = (weight + q - 1) / q;
+            }
+        }
+    }
     return MI355_SPMV_OK;
 }
 

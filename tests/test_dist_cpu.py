@@ -129,6 +129,48 @@ def test_allgatherv_world2_gloo(tmp_path, balance):
     assert sorted(os.listdir(tmp_path)) == ["rank0.ok", "rank1.ok"]
 
 
+def _worker_views(rank, world, port, out_dir):
+    """The flow of bench.py / mi355_spmv_dist_create_rank on the CPU: cuts on chunk boundaries (the library's
+    partition rule), zero-copy block VIEWS that keep the 16-byte phase (Ap_l[0] != 0), two sub-blocks per rank,
+    in-place exchange into the full-length y."""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as g
+    from oracle.oracle import Oracle
+    sp = g.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.RandomState(9)                                   # same matrix on every rank
+    Ap, Aj, Ax = random_csr(rng, 4003, 500, 21, long_row=7000)
+    x = (rng.rand(500) * 2 - 1).astype(np.float32)
+    Ap_t, Aj_t, Ax_t = map(torch.from_numpy, (Ap, Aj, Ax))
+    sub = 2
+    rows = sp.dist.partition_rows(Ap_t, world * sub, unit=64)        # 64-row chunks of a uniform plan
+    y_full = torch.full((4003,), float("nan"))
+    phases = []
+    for b in range(rank * sub, (rank + 1) * sub):
+        a, j, v, lo = sp.dist.block_view(Ap_t, Aj_t, Ax_t, rows[b], rows[b + 1])
+        phases.append(int(a[0]))
+        y_full[rows[b]:rows[b + 1]] = torch.from_numpy(Oracle().spmv_serial(a.numpy(), j.numpy(), v.numpy(), x))
+    rank_cuts = [rows[r * sub] for r in range(world)] + [rows[-1]]
+    lo, hi = rank_cuts[rank], rank_cuts[rank + 1]
+    sp.dist.allgatherv(y_full[lo:hi].clone(), y_full, rank_cuts)
+    want = Oracle().spmv_serial(Ap, Aj, Ax, x)
+    ok = np.array_equal(y_full.numpy(), want) and all(0 <= ph <= 3 for ph in phases)
+    ok = ok and all(r % 64 == 0 or r == 4003 for r in rows)
+    open(os.path.join(out_dir, "rank%d.%s" % (rank, "ok" if ok else "bad")), "w").close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_flow_with_block_views_world2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_views, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["rank0.ok", "rank1.ok"]
+
+
 def _worker_equal(rank, world, port, out_dir):
     import sys
     sys.path.insert(0, ROOT)
