@@ -117,7 +117,8 @@ struct Part {                 // one row block and its plan
 struct Dev {
     int device = 0;           // HIP ordinal
     hipStream_t compute = nullptr, comm = nullptr;
-    hipEvent_t start = nullptr, done = nullptr;
+    hipStream_t side = nullptr;      // odd sub-blocks run here: the ramp of block s + 1 overlaps the drain of block s
+    hipEvent_t start = nullptr, done = nullptr, side_done = nullptr;
     std::vector<hipEvent_t> part_done;
     void* x = nullptr;        // remote devices (LOCAL mode): replicated x / full-length y, owned
     void* y = nullptr;
@@ -172,6 +173,8 @@ int destroy_impl(mi355_spmv_dist* d) {
         if (v.nccl && api) (void)api->CommDestroy(v.nccl);
         if (v.compute) (void)hipStreamDestroy(v.compute);
         if (v.comm) (void)hipStreamDestroy(v.comm);
+        if (v.side) (void)hipStreamDestroy(v.side);
+        if (v.side_done) (void)hipEventDestroy(v.side_done);
         if (v.start) (void)hipEventDestroy(v.start);
         if (v.done) (void)hipEventDestroy(v.done);
         for (hipEvent_t e : v.part_done) (void)hipEventDestroy(e);
@@ -250,10 +253,14 @@ int make_parts(mi355_spmv_dist* d, int first, int count, const void* Ap_src, con
 int make_streams(mi355_spmv_dist* d) {
     for (Dev& v : d->devs) {
         MI355_HIP_TRY(hipSetDevice(v.device));
+        if (d->world > 1 || d->sub_blocks > 1) MI355_HIP_TRY(hipEventCreateWithFlags(&v.start, hipEventDisableTiming));
+        if (d->sub_blocks > 1) {
+            MI355_HIP_TRY(hipStreamCreateWithFlags(&v.side, hipStreamNonBlocking));
+            MI355_HIP_TRY(hipEventCreateWithFlags(&v.side_done, hipEventDisableTiming));
+        }
         if (d->world > 1) {
             MI355_HIP_TRY(hipStreamCreateWithFlags(&v.compute, hipStreamNonBlocking));
             MI355_HIP_TRY(hipStreamCreateWithFlags(&v.comm, hipStreamNonBlocking));
-            MI355_HIP_TRY(hipEventCreateWithFlags(&v.start, hipEventDisableTiming));
             MI355_HIP_TRY(hipEventCreateWithFlags(&v.done, hipEventDisableTiming));
             v.part_done.resize(size_t(d->sub_blocks));
             for (hipEvent_t& e : v.part_done) MI355_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -463,15 +470,17 @@ int mi355_spmv_dist_execute(mi355_spmv_dist* d, const void* Ax, const void* x, v
     if (multi && !api) return MI355_SPMV_ENOTSUP;
     // everything the caller's stream has queued (its previous execute, the scatter / replicate copies above)
     // comes before this execute's work on the other streams
-    if (multi) {
+    const bool two = d->sub_blocks > 1;          // two compute streams per GPU: even / odd sub-blocks
+    if (multi || two) {
         Dev& h = d->devs[size_t(d->home)];
         MI355_HIP_TRY(hipSetDevice(h.device));
         MI355_HIP_TRY(hipEventRecord(h.start, user));
         for (int i = 0; i < n_dev; ++i) {
             Dev& v = d->devs[size_t(i)];
             MI355_HIP_TRY(hipSetDevice(v.device));
-            if (i != d->home) MI355_HIP_TRY(hipStreamWaitEvent(v.compute, h.start, 0));
-            MI355_HIP_TRY(hipStreamWaitEvent(v.comm, h.start, 0));
+            if (multi && i != d->home) MI355_HIP_TRY(hipStreamWaitEvent(v.compute, h.start, 0));
+            if (multi) MI355_HIP_TRY(hipStreamWaitEvent(v.comm, h.start, 0));
+            if (two) MI355_HIP_TRY(hipStreamWaitEvent(v.side, h.start, 0));
         }
     }
     const ncclDataType_t dt = d->val_type == MI355_VAL_F64 ? ncclFloat64 : ncclFloat32;
@@ -480,7 +489,7 @@ int mi355_spmv_dist_execute(mi355_spmv_dist* d, const void* Ax, const void* x, v
             Dev& v = d->devs[size_t(i)];
             Part& p = d->parts[size_t(i * d->sub_blocks + s)];
             const bool is_home = i == d->home;
-            hipStream_t cs = (is_home || !multi) ? user : v.compute;
+            hipStream_t cs = (two && (s & 1)) ? v.side : ((is_home || !multi) ? user : v.compute);
             MI355_HIP_TRY(hipSetDevice(v.device));
             if (p.n_rows > 0) {
                 // home device (and every rank): views of the caller's arrays; remote devices: their copies
@@ -512,6 +521,13 @@ int mi355_spmv_dist_execute(mi355_spmv_dist* d, const void* Ax, const void* x, v
             }
             MI355_RCCL_TRY(api, api->GroupEnd());
         }
+    }
+    if (two && !multi) {
+        // one GPU, several blocks: the caller's stream continues behind the side stream's blocks
+        Dev& v = d->devs[size_t(d->home)];
+        MI355_HIP_TRY(hipSetDevice(v.device));
+        MI355_HIP_TRY(hipEventRecord(v.side_done, v.side));
+        MI355_HIP_TRY(hipStreamWaitEvent(user, v.side_done, 0));
     }
     if (multi) {
         // the caller's stream continues once every GPU of this process holds the whole y
