@@ -60,6 +60,7 @@ static void parse_knobs(Knobs& k) {
     geti("MI355_MERGE_TPS", k.merge_tps);
     geti("MI355_MERGE_SEARCH_LANES", k.merge_search_lanes);
     geti("MI355_MERGE_FUSED", k.merge_fused);
+    geti("MI355_MERGE_ROWS", k.merge_rows);
     if (k.window > 1) k.window = 1;
     if (k.balance > 1) k.balance = 1;
 }
@@ -80,14 +81,16 @@ template <typename off_t>
 __global__ __launch_bounds__(kBlock) void probe_kernel(int32_t n_rows, const off_t* __restrict__ Ap,
                                                        const int32_t* __restrict__ Aj, long long* out) {
     // out[0], out[1]: band [lo, hi] over the first/last column of 256 rows;
-    // out[2 + 32 t + i]: (column - row) at 32 positions spread over row t's nonzeros (LLONG_MAX = none)
-    __shared__ long long s_lo[kBlock / kWave], s_hi[kBlock / kWave];
+    // out[2 + 32 t + i]: (column - row) at 32 positions spread over row t's nonzeros (LLONG_MAX = none);
+    // out[2 + 32 * 256], out[3 + 32 * 256]: shortest / longest of the 256 rows
+    __shared__ long long s_lo[kBlock / kWave], s_hi[kBlock / kWave], s_lmin[kBlock / kWave], s_lmax[kBlock / kWave];
     const int tid = threadIdx.x;
-    long long lo = LLONG_MAX, hi = LLONG_MIN;
+    long long lo = LLONG_MAX, hi = LLONG_MIN, lmin = LLONG_MAX, lmax = 0;
     for (int i = 0; i < kProbePerRow; ++i) out[2 + tid * kProbePerRow + i] = LLONG_MAX;
     if (n_rows > 0) {
         const int64_t r = (int64_t(n_rows - 1) * tid) / (kBlock - 1);
         const off_t s = Ap[r], e = Ap[r + 1];
+        lmin = lmax = (long long)(e - s);
         if (e > s) {
             const long long first = Aj[s], last = Aj[e - 1];
             lo = min(first, last) - r;
@@ -104,19 +107,27 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(int32_t n_rows, const off
     for (int o = 32; o >= 1; o >>= 1) {
         lo = min(lo, __shfl_xor(lo, o, kWave));
         hi = max(hi, __shfl_xor(hi, o, kWave));
+        lmin = min(lmin, __shfl_xor(lmin, o, kWave));
+        lmax = max(lmax, __shfl_xor(lmax, o, kWave));
     }
     if ((tid & (kWave - 1)) == 0) {
         s_lo[tid / kWave] = lo;
         s_hi[tid / kWave] = hi;
+        s_lmin[tid / kWave] = lmin;
+        s_lmax[tid / kWave] = lmax;
     }
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < kBlock / kWave; ++w) {
             lo = min(lo, s_lo[w]);
             hi = max(hi, s_hi[w]);
+            lmin = min(lmin, s_lmin[w]);
+            lmax = max(lmax, s_lmax[w]);
         }
         out[0] = lo;
         out[1] = hi;
+        out[2 + kBlock * kProbePerRow] = lmin;
+        out[3 + kBlock * kProbePerRow] = lmax;
     }
 }
 
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(int32_t n_rows, const off
 // for the life of the process instead of a hipMalloc + hipFree (an implicit device synchronisation) per plan —
 // the one-shot entry points create a plan per call, like the reference's kinds.  plan_create holds the lock
 // while it uses the buffer.
-constexpr size_t kAnalysisWords = 2 + size_t(kBlock) * kProbePerRow + 2;
+constexpr size_t kAnalysisWords = 2 + size_t(kBlock) * kProbePerRow + 2 + 2;   // band, samples, row lengths, 2 spare words
 static std::mutex g_analysis_mutex;
 static long long* g_analysis_buf[64] = {};
 
@@ -148,8 +159,10 @@ int probe_structure(Plan& p) {
     p.probe_n = 0;
     p.n_seg = 0;
     if (p.n_rows <= 0 || p.nnz <= 0) return MI355_SPMV_OK;
-    constexpr size_t N = 2 + size_t(kBlock) * kProbePerRow;
+    constexpr size_t NS = 2 + size_t(kBlock) * kProbePerRow;   // band + samples
+    constexpr size_t N = NS + 2;                                // + shortest / longest sampled row
     static_assert(size_t(kBlock) * kProbePerRow <= sizeof(p.probe_off) / sizeof(p.probe_off[0]), "probe buffer");
+    p.probe_len_min = p.probe_len_max = 0;
     std::lock_guard<std::mutex> lock(g_analysis_mutex);
     long long* d_out = analysis_buffer();
     if (!d_out) { set_error("probe_structure: no device scratch"); return MI355_SPMV_ENOMEM; }
@@ -171,8 +184,10 @@ int probe_structure(Plan& p) {
         p.band_lo = h[0];
         p.band_hi = h[1];
         p.probe_ok = true;
-        for (size_t i = 2; i < N; ++i)
+        for (size_t i = 2; i < NS; ++i)
             if (h[i] != LLONG_MAX) p.probe_off[p.probe_n++] = h[i];
+        p.probe_len_min = h[NS];
+        p.probe_len_max = h[NS + 1];
         p.probe_sorted = false;    // sorted on first use (cluster_bands): most plans never need the samples
     }
     delete[] h;

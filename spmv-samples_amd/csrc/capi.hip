@@ -462,8 +462,11 @@ int mi355_spmv_plan_merge_coords(mi355_spmv_plan* h, int64_t* tile_row, int64_t*
     if (!h || !tile_row || !tile_nnz) { set_error("plan_merge_coords: null argument"); return MI355_SPMV_EINVAL; }
     Plan& p = h->p;
     if (p.kind != MI355_KIND_MERGE) { set_error("plan_merge_coords: not a merge plan"); return MI355_SPMV_EINVAL; }
-    if (!p.coords_valid) { set_error("plan_merge_coords: no execute yet"); return MI355_SPMV_EINVAL; }
     MI355_HIP_TRY(hipDeviceSynchronize());
+    if (p.merge_rows) {        // (this plan's executes find run boundaries only: compute all tile coordinates now)
+        const int st = merge_compute_coords(p);
+        if (st != MI355_SPMV_OK) return st;
+    } else if (!p.coords_valid) { set_error("plan_merge_coords: no execute yet"); return MI355_SPMV_EINVAL; }
     const size_t n = size_t(p.n_tiles + 1);
     int32_t* rows32 = new (std::nothrow) int32_t[n];
     if (!rows32) return MI355_SPMV_ENOMEM;

@@ -67,6 +67,7 @@ struct Knobs {
     int merge_block = 0;       // MI355_MERGE_BLOCK           256 | 512
     int merge_tps = 0;         // MI355_MERGE_TPS             tiles per run
     int merge_search_lanes = 0;// MI355_MERGE_SEARCH_LANES    1 | 4 | 16
+    int merge_rows = -1;       // MI355_MERGE_ROWS            0 = never the row-parallel run kernel, 1 = always
     int merge_fused = -1;      // MI355_MERGE_FUSED           0 = never the single-launch small-grid kernel, 1 = whenever legal
     char text[160] = "";       // the non-default ones, "NAME=value ..." (as read)
 };
@@ -101,6 +102,8 @@ struct Plan {
     int64_t tile_items, n_tiles;
     int64_t tiles_per_super, n_super;   // consecutive tiles one workgroup walks; number of such groups
     bool coords_valid;
+    bool merge_rows;            // MERGE: regular matrix -> runs are summed row-parallel (merge_rows_kernel)
+    int64_t probe_len_min, probe_len_max;   // shortest / longest of the probe's sampled rows (valid when probe_ok)
     int semiring;               // MERGE: MI355_SEMIRING_* (0 = plus-times)
     double alpha, beta;         // y = alpha * A x + beta * y (1, 0 by default)
     // structure probe (plan creation): band of (column - row) seen on sampled rows
@@ -158,6 +161,7 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
 template <typename off_t, typename val_t>
 int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s);
 
+int merge_compute_coords(Plan& p);   // MERGE: run the search kernel now (null stream, synchronises)
 int probe_structure(Plan& p);
 int pick_window_elems(Plan& p, int64_t rows_per_workgroup);
 int64_t segment_rows_fit(const Plan& p);

@@ -46,6 +46,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 #include "row_dot.hpp"
@@ -455,6 +456,113 @@ __global__ __launch_bounds__(BLOCK) void merge_tile_kernel(
     }
 }
 
+// ---- K7r: a run of a REGULAR matrix, row-parallel ------------------------------------------------------
+// The merge-path cut decides WHICH nonzeros and row ends a workgroup owns (the run: a fixed number of merge items,
+// whatever the row lengths — the reference's decomposition, agent_spmv_orig.cuh:697-719); how the workgroup sums them
+// is free.  On a matrix whose rows are alike and not short (plan: shape_merge, merge_rows) the item-by-item machinery
+// of K7 — products through LDS, a search per thread, a segmented scan per tile — costs ~460 instructions per wave and
+// tile and holds the kernel at 4.4 TB/s.  Here the run is handed to the row-chunk body of the CSR-vector kind
+// (xwindow.hpp: T lanes per row, 16-byte loads straight into registers, window of x, results swept from LDS): the
+// rows that END in the run are stored, the partial sum of the row still open at its end becomes the run's carry, and a
+// row that began in an earlier run contributes the part that lies in this one (the fix-up adds the earlier carries,
+// exactly as for K7).  The workgroup finds its two diagonals itself.  Runs with more rows than the LDS layout holds
+// (stretches of empty rows) are walked in pieces.
+constexpr int kMergeRowsCap = 1984;    // rows per piece: bounds + results fit 16 KB next to the window
+
+// SEARCH: the workgroup finds its two diagonals itself (grids of a few rounds); else run_row / run_nnz hold the run
+// boundaries, found by the search kernel on n_super + 1 diagonals (every workgroup of a big grid would otherwise pay
+// the chain of dependent loads at its start).
+template <int BLOCK, int R, bool WINDOW, bool SEARCH, typename off_t, typename val_t>
+__global__ __launch_bounds__(BLOCK, 3) void merge_rows_kernel(
+    int32_t n_rows, int32_t n_cols, int64_t nnz_begin, int64_t nnz, const off_t* __restrict__ Ap,
+    const int32_t* __restrict__ Aj_arg, const val_t* __restrict__ Ax_arg, const val_t* __restrict__ x_arg,
+    val_t* __restrict__ y_arg, int64_t tile_items, const int32_t* __restrict__ run_row, const int64_t* __restrict__ run_nnz,
+    int32_t* __restrict__ carry_row, val_t* __restrict__ carry_val,
+    int64_t n_tiles, int32_t tiles_per_super, int32_t window_cap, BandHint hint, val_t alpha, val_t beta) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
+    __shared__ int s_red[2];
+    __shared__ int64_t s_diag[4];            // (row, nnz) of the run's first and last diagonal
+    ChunkScratch<val_t> scr(s_dyn, window_cap, kMergeRowsCap);
+    scr.alpha = alpha;
+    scr.beta = beta;
+    const unsigned sup = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x;
+    const int64_t first = int64_t(sup) * tiles_per_super;
+    const int64_t last = min(first + tiles_per_super, n_tiles);
+    if constexpr (!SEARCH) {
+        if (tid == 0) {
+            s_diag[0] = run_row[sup];
+            s_diag[1] = run_nnz[sup];
+            s_diag[2] = run_row[sup + 1];
+            s_diag[3] = run_nnz[sup + 1];
+        }
+        __syncthreads();
+    } else {   // the two diagonals, 16 lanes each (lanes 0..31 of wave 0; the other lanes of that wave repeat the second)
+        const int64_t items = int64_t(n_rows) + (nnz - nnz_begin);
+        if (tid < kWave) {
+            const int which = min(tid / 16, 1);
+            int64_t diag = (which ? last : first) * tile_items;
+            if (diag > items) diag = items;
+            const int64_t lo = merge_search_group<16, off_t>(diag, n_rows, nnz_begin, nnz, Ap, tid & 15, tid & 48);
+            if ((tid & 15) == 0 && tid < 32) {
+                s_diag[2 * which] = lo;
+                s_diag[2 * which + 1] = nnz_begin + diag - lo;
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t row_lo = uniform_i64(s_diag[0]), y_first = uniform_i64(s_diag[1]);
+    const int64_t row_last = uniform_i64(s_diag[2]), y_last = uniform_i64(s_diag[3]);
+    // rows [row_lo, row_last) END in this run; row_last (if it exists) is open at its end
+    const int64_t n_store_all = row_last - row_lo;
+    const int64_t n_all = n_store_all + (row_last < n_rows ? 1 : 0);
+    const int64_t base = y_first & ~int64_t(3);
+    const int64_t left = nnz - base;
+    const int32_t nnz_c = int32_t(left < kRel32Limit ? left : kRel32Limit);
+    val_t carry = val_t(0);
+    for (int64_t pb = 0; pb < n_all; pb += kMergeRowsCap) {          // (uniform; one piece unless the run holds > 1 984 rows)
+        const int64_t pe = min(pb + int64_t(kMergeRowsCap), n_all);
+        const int rows = int(pe - pb);
+        // opaque copies of the operand pointers, once per piece (see light_rows.hip: keeps per-thread addresses from
+        // being hoisted out of this loop and spilled)
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        zero = __builtin_amdgcn_readfirstlane(zero);
+        const int32_t* const Aj_c = Aj_arg + zero + base;
+        const val_t* const Ax_c = Ax_arg + zero + base;
+        const val_t* const x = x_arg + zero;
+        val_t* const y = y_arg + zero;
+        // bounds of the piece's rows, clipped to the run's nonzeros [y_first, y_last), relative to base
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        for (int i = t2; i <= rows; i += BLOCK) {
+            int64_t b = int64_t(Ap[min(row_lo + pb + i, int64_t(n_rows))]);
+            b = b < y_first ? y_first : (b > y_last ? y_last : b);
+            scr.s_b[i] = int32_t(b - base);
+        }
+        for (int i = t2; i < rows / 32 + 1; i += BLOCK) scr.long_map[i] = 0u;
+        scr.store_rows = int(min(pe, n_store_all) - pb);              // the open row's partial stays in s_y
+        __syncthreads();
+        const int64_t rb = row_lo + pb, re = row_lo + pe;
+        auto first_last = [&](int64_t r, int& fc, int& lc) {
+            const int32_t s = scr.s_b[r - rb], e = scr.s_b[r - rb + 1];
+            if (e <= s) return false;
+            fc = Aj_c[s];
+            lc = Aj_c[e - 1];
+            return true;
+        };
+        auto stage = [&] { return stage_x_window<val_t>(rb, re, n_cols, first_last, x, scr.s_x, window_cap, s_red, hint); };
+        chunk_rows_any<BLOCK, 2, R, WINDOW, true, val_t>(rb, re, nnz_c, Aj_c, Ax_c, x, y, stage, scr);
+        __syncthreads();
+        if (pe == n_all && n_all > n_store_all) carry = uniform_val(scr.s_y[rows - 1]);   // (one LDS word: scalar register)
+        __syncthreads();                                                       // ... read before the next piece refills it
+    }
+    if (tid == 0) {
+        carry_row[sup] = int32_t(row_last);       // == n_rows: no row is open (the fix-up skips it)
+        carry_val[sup] = carry;
+    }
+}
+
 // ---- K8: add the carries of rows that straddle runs ------------------------------------
 template <int S, typename val_t>
 __global__ __launch_bounds__(kBlock) void merge_fixup_kernel(
@@ -489,6 +597,18 @@ static bool merge_search_in_kernel(const Plan& p) {
     return p.n_super <= int64_t(kCus) * 8;
 }
 
+// Row-parallel runs (merge_rows_kernel) for a matrix whose rows are alike and not short — the probe's 256 sampled rows
+// all hold between a quarter of and four times the mean, the mean is at least 8 — and big enough for runs of 16 K+ items
+// (on a small matrix a run is a tile or two: the window and the two diagonals cost more than they are worth — cant
+// stand-in 40.6 us against 19.5 with the item walk).  MI355_MERGE_ROWS = 0 | 1 overrides.
+static bool merge_rows_wanted(const Plan& p) {
+    if (p.knob.merge_rows >= 0) return p.knob.merge_rows != 0;
+    if (!p.probe_ok || p.n_rows <= 0) return false;
+    if (p.tiles_per_super * p.tile_items < 16384) return false;
+    const int64_t mean = (p.nnz - p.nnz_begin) / p.n_rows;
+    return mean >= 8 && p.probe_len_min * 4 >= mean && p.probe_len_max <= 4 * mean + 8;
+}
+
 void shape_merge(Plan& p) {
     // tuning knobs: MI355_MERGE_TPS = tiles per run (and MI355_SPMV_WINDOW = 0|1, analyze.hip)
     // 256 threads x 8 items or (MI355_MERGE_BLOCK=512) 512 threads x 4 items: the same 2 044-item tiles
@@ -510,15 +630,41 @@ void shape_merge(Plan& p) {
     p.grid_blocks = p.n_super;
     // a window of x only pays when a run is long enough to amortise staging it, and
     // when the band the probe saw (plus the rows of a run) fits
+    bool several_bands = false;
     {
         const int64_t mean1 = 1 + (p.n_rows > 0 ? (p.nnz - p.nnz_begin) / p.n_rows : 0);
         const int64_t rows_per_run = tps * p.tile_items / mean1 + 1;
         p.window_elems = (tps * p.tile_items >= 8192) ? pick_window_elems(p, rows_per_run) : 0;
+        several_bands = p.n_seg >= 2;
         if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }   // several bands: this kind keeps to global gathers
     }
     p.n_kernels = (p.n_super > 1 ? 2 : 1) + ((merge_search_in_kernel(p) && p.block_threads == kBlock) ? 0 : 1);
+    // (a matrix whose columns sit in several far-apart bands — the 3-D stencil — keeps the item walk: this kind stages
+    // one window only, and row-parallel runs on plain gathers measured 720 us against 650-700 on the C4 stand-in)
+    p.merge_rows = p.block_threads == kBlock && !several_bands && merge_rows_wanted(p);
+    if (p.merge_rows) {
+        p.n_kernels = (p.n_super > 1 ? 2 : 1) + (merge_search_in_kernel(p) ? 0 : 1);
+        snprintf(p.main_kernel, sizeof(p.main_kernel), "merge_rows_kernel");
+        return;
+    }
     p.coords_valid = false;
     snprintf(p.main_kernel, sizeof(p.main_kernel), "merge_tile_kernel");
+}
+
+// The tile coordinates on demand (mi355_spmv_plan_merge_coords on a plan whose executes do not produce them: the
+// row-parallel run kernel only ever finds its own two diagonals).
+int merge_compute_coords(Plan& p) {
+    if (p.n_rows == 0 || p.n_tiles == 0) return MI355_SPMV_OK;
+    const unsigned g = unsigned(((p.n_tiles + 1) * 4 + kBlock - 1) / kBlock);
+    if (p.off_type == MI355_OFF_I32)
+        hipLaunchKernelGGL((merge_search_kernel<4, int32_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows, p.nnz_begin, p.nnz,
+                           static_cast<const int32_t*>(p.Ap), p.tile_items, p.n_tiles, p.tile_row, p.tile_nnz);
+    else
+        hipLaunchKernelGGL((merge_search_kernel<4, int64_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows, p.nnz_begin, p.nnz,
+                           static_cast<const int64_t*>(p.Ap), p.tile_items, p.n_tiles, p.tile_row, p.tile_nnz);
+    MI355_HIP_TRY(hipGetLastError());
+    MI355_HIP_TRY(hipStreamSynchronize(nullptr));
+    return MI355_SPMV_OK;
 }
 
 template <typename off_t, typename val_t, typename mat_t>
@@ -530,6 +676,46 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
     const bool vec = aligned && p.nnz >= 4;
     const bool wide = p.block_threads == kWideBlock && p.semiring == MI355_SEMIRING_PLUS_TIMES;
     // the tile kernel finds its run's coordinates itself (no search kernel in front) on the 16-byte path with 256 threads
+    // regular matrix: row-parallel runs (plus-times, one value type, 16-byte path); the kernel searches its own diagonals
+    if constexpr (std::is_same<val_t, mat_t>::value) {
+        if (p.merge_rows && vec && p.semiring == MI355_SEMIRING_PLUS_TIMES) {
+            constexpr int RR = sizeof(val_t) == 4 ? 4 : 2;
+            const int32_t capw = (int32_t)p.window_elems;
+            const size_t lds = chunk_lds_bytes(capw, kMergeRowsCap, sizeof(val_t));
+            const BandHint hint_r{p.band_lo, p.band_hi, p.window_from_band};
+            const dim3 grid_r((unsigned)p.n_super);
+            // run boundaries: searched in the kernel on small grids, by the search kernel (n_super + 1 diagonals of
+            // tiles_per_super tiles each; the last one clamps to the end of the merge) on big ones
+            const bool in_kernel = merge_search_in_kernel(p);
+            if (!in_kernel) {
+                const int64_t diagonals = p.n_super + 1;
+                const unsigned gs = unsigned((diagonals * 4 + kBlock - 1) / kBlock);
+                hipLaunchKernelGGL((merge_search_kernel<4, off_t>), dim3(gs), dim3(kBlock), 0, s, p.n_rows, p.nnz_begin, p.nnz, Ap,
+                                   p.tile_items * p.tiles_per_super, p.n_super, p.tile_row, p.tile_nnz);
+                MI355_HIP_TRY(hipGetLastError());
+                p.coords_valid = false;       // (the arrays now hold RUN boundaries, not tile coordinates)
+            }
+#define MI355_MERGE_ROWS_LAUNCH(WIN_, SEARCH_)                                                                     \
+    do {                                                                                                           \
+        if (const int st = allow_dynamic_lds((const void*)merge_rows_kernel<kBlock, RR, WIN_, SEARCH_, off_t, val_t>, lds)) return st; \
+        hipLaunchKernelGGL((merge_rows_kernel<kBlock, RR, WIN_, SEARCH_, off_t, val_t>), grid_r, dim3(kBlock), lds, s, p.n_rows, \
+                           p.n_cols, p.nnz_begin, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_items, p.tile_row, p.tile_nnz,   \
+                           p.carry_row, static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super,    \
+                           capw, hint_r, (val_t)p.alpha, (val_t)p.beta);                                            \
+    } while (0)
+            if (capw > 0) { if (in_kernel) MI355_MERGE_ROWS_LAUNCH(true, true); else MI355_MERGE_ROWS_LAUNCH(true, false); }
+            else { if (in_kernel) MI355_MERGE_ROWS_LAUNCH(false, true); else MI355_MERGE_ROWS_LAUNCH(false, false); }
+#undef MI355_MERGE_ROWS_LAUNCH
+            MI355_HIP_TRY(hipGetLastError());
+            if (p.n_super > 1) {
+                const unsigned g = unsigned((p.n_super + kBlock - 1) / kBlock);
+                hipLaunchKernelGGL((merge_fixup_kernel<MI355_SEMIRING_PLUS_TIMES, val_t>), dim3(g), dim3(kBlock), 0, s, p.n_super,
+                                   p.n_rows, p.carry_row, static_cast<const val_t*>(p.carry_val), y, (val_t)p.alpha);
+                MI355_HIP_TRY(hipGetLastError());
+            }
+            return MI355_SPMV_OK;
+        }
+    }
     const bool fused = !reuse && vec && !wide && merge_search_in_kernel(p);
     if (!reuse && !fused) {
         const int64_t diagonals = p.n_tiles + 1;

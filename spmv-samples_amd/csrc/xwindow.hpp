@@ -268,6 +268,10 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
     return int64_t((uint64_t(hi) << 32) | lo);
 }
 
+// ... and a float / double that is the same in every lane (an LDS word every thread reads).
+__device__ __forceinline__ float uniform_val(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ double uniform_val(double v) { return __longlong_as_double(uniform_i64(__double_as_longlong(v))); }
+
 // Row offsets of either width behind one kernel signature (a uniform branch per load, in prologues only).
 struct ApView {
     const void* p;
@@ -315,6 +319,8 @@ struct ChunkScratch {
     val_t alpha, beta;    // y = alpha * (A x) + beta * y   (1, 0 unless mi355_spmv_plan_set_alpha_beta)
     int long_steps = kLongSteps;
     int64_t giant_len = 0;   // > 0: rows longer than this are summed by giant_rows.hpp, this workgroup stores 0 for them
+    int store_rows = -1;     // >= 0: only the first store_rows results go to y (the merge kind's row-parallel runs keep
+                             // the partial sum of a row that continues in the next run: it stays in s_y for the caller)
     __device__ ChunkScratch(unsigned char* base, int window_elems, int rows) {
         s_x = reinterpret_cast<val_t*>(base);
         base += lds_align16(size_t(window_elems) * sizeof(val_t));
@@ -678,19 +684,20 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     constexpr int PER16 = 16 / int(sizeof(val_t));
     const val_t alpha = scr.alpha, beta = scr.beta;
     const bool scaled = (alpha != val_t(1)) || (beta != val_t(0));   // uniform
+    const int n_store = scr.store_rows >= 0 ? scr.store_rows : rows;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));   // (opaque: keeps the sweep's per-thread offsets from being hoisted out of a persistent loop)
     if (!scaled && (reinterpret_cast<uintptr_t>(yc) & 15u) == 0) {
         using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
-        const int full = rows / PER16;
+        const int full = n_store / PER16;
         for (int g = tid; g < full; g += BLOCK)
             __builtin_nontemporal_store(*reinterpret_cast<const v16*>(scr.s_y + g * PER16),
                                         reinterpret_cast<v16*>(yc + g * PER16));
-        for (int i = full * PER16 + tid; i < rows; i += BLOCK) yc[i] = scr.s_y[i];
+        for (int i = full * PER16 + tid; i < n_store; i += BLOCK) yc[i] = scr.s_y[i];
     } else if (!scaled) {
-        for (int i = tid; i < rows; i += BLOCK) yc[i] = scr.s_y[i];
+        for (int i = tid; i < n_store; i += BLOCK) yc[i] = scr.s_y[i];
     } else {
-        for (int i = tid; i < rows; i += BLOCK) {
+        for (int i = tid; i < n_store; i += BLOCK) {
             val_t v = alpha * scr.s_y[i];
             if (beta != val_t(0)) v += beta * yc[i];
             yc[i] = v;

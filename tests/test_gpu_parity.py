@@ -724,3 +724,43 @@ def test_fp32_matrix_under_fp64_vectors_merge(sp, oracle, off):
             sp.Plan(kind, 20011, 5000, int(cases[0][0][-1]), dAp, dAj, torch.float64, mat_dtype=torch.float32)
     with pytest.raises(RuntimeError, match="not supported"):
         sp.Plan("merge", 20011, 5000, int(cases[0][0][-1]), dAp, dAj, torch.float32, mat_dtype=torch.float64)
+
+
+def test_merge_on_a_regular_matrix_takes_row_parallel_runs(sp, oracle):
+    """A big matrix whose rows are alike (the target's shape): the merge kind keeps its merge-path runs but sums each
+    run row-parallel (merge_rows_kernel).  Every row inside the bound, alpha / beta, bitwise reproducible, the
+    tile coordinates still available (computed on demand) and still the oracle's; a ragged matrix keeps the item walk."""
+    m = sp.synth.banded_fixed(1_200_000, 32, 900, seed=6, device=DEV)    # (big enough for runs of 16 tiles)
+    x = sp.synth.dense_vector(m.n_cols, torch.float32, 6, DEV)
+    p = sp.Plan("merge", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, torch.float32)
+    info = p.info()
+    if not any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB"):
+        assert info["main_kernel"] == "merge_rows_kernel", info
+    y = torch.full((m.n_rows,), float("nan"), device=DEV)
+    p.execute(m.Ax, x, y)
+    torch.cuda.synchronize()
+    Ap, Aj, Ax = m.numpy()
+    assert_parity(oracle, Ap, Aj, Ax, x.cpu().numpy(), y.cpu().numpy())
+    y2 = torch.full((m.n_rows,), float("nan"), device=DEV)
+    p.execute(m.Ax, x, y2)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    rows, nz = p.merge_coords()
+    xs, ys = oracle.merge_tile_coords(Ap, info["tile_items"])
+    assert np.array_equal(rows, xs) and np.array_equal(nz, ys)
+    p.set_alpha_beta(3.0, -0.5)
+    y0 = sp.synth.dense_vector(m.n_rows, torch.float32, 7, DEV)
+    y3 = y0.clone()
+    p.execute(m.Ax, x, y3)
+    torch.cuda.synchronize()
+    p.destroy()
+    y64, bound = parity_bound(oracle, Ap, Aj, Ax, x.cpu().numpy())
+    want = 3.0 * y64 - 0.5 * y0.cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(y3.cpu().numpy() - want) <= 3.0 * bound + 1e-6 * np.abs(want) + 1e-30)
+    rng = np.random.RandomState(3)
+    Ap2, Aj2, Ax2 = random_csr(rng, 200_000, 5000, 40)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    p = sp.Plan("merge", 200_000, 5000, int(Ap2[-1]), d(Ap2), d(Aj2), torch.float32)
+    if "MI355_MERGE_ROWS" not in os.environ:
+        assert p.info()["main_kernel"] == "merge_tile_kernel"
+    p.destroy()
