@@ -639,8 +639,9 @@ void shape_merge(Plan& p) {
         if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }   // several bands: this kind keeps to global gathers
     }
     p.n_kernels = (p.n_super > 1 ? 2 : 1) + ((merge_search_in_kernel(p) && p.block_threads == kBlock) ? 0 : 1);
-    // (a matrix whose columns sit in several far-apart bands — the 3-D stencil — keeps the item walk: this kind stages
-    // one window only, and row-parallel runs on plain gathers measured 720 us against 650-700 on the C4 stand-in)
+    // (a matrix whose columns sit in several far-apart bands — the 3-D stencil — keeps the item walk: row-parallel runs
+    // on plain gathers measured 720 us against 650-700 on the C4 stand-in, and with the bands staged per piece of a run
+    // 681 against 727 on one box, with four spilling kernels: not kept)
     p.merge_rows = p.block_threads == kBlock && !several_bands && merge_rows_wanted(p);
     if (p.merge_rows) {
         p.n_kernels = (p.n_super > 1 ? 2 : 1) + (merge_search_in_kernel(p) ? 0 : 1);
