@@ -171,27 +171,65 @@ class Runner:
             flag = torch.tensor([ok])
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())
+        self._fb = (sp, rank, world, sub_blocks, rows, chunks, nnzs, shape, r0, Ap_l, Aj_l, Ax_l, flags)
         if not ok:
-            # Safety net so that a scaling run still measures something: the same row blocks through the C ABI's
-            # block plans, the exchange through torch.distributed's RCCL group instead of the library's own.
-            if self.plan is not None:
-                self.plan.destroy()
-            sys.stderr.write("bench.py: mi355_spmv_dist_create_rank failed (%s); exchanging y through torch.distributed\n" % err)
-            self.exchange = "FALLBACK torch.distributed over RCCL (the library's own communicator failed: %s)" % (err or "on another rank")
-            self.pg = dist.new_group(backend="nccl")
-            self.rank_cuts = [rows[r * sub_blocks] for r in range(world)] + [rows[-1]]
-            self.blocks = []
-            for b in range(rank * sub_blocks, (rank + 1) * sub_blocks):
-                a, j, v, _ = sp.dist.block_view(Ap_l, Aj_l, Ax_l, rows[b] - r0, rows[b + 1] - r0)
-                if rows[b + 1] == rows[b]:
-                    continue
-                cb = chunks[b] if chunks is not None else 0
-                nc = (chunks[b + 1] - chunks[b]) if chunks is not None else 0
-                pl = sp.Plan.block(kind, shape, rows[b], cb, nc, nnzs[b], rows[b + 1] - rows[b], m.n_cols,
-                                   int(a[-1].item()), a, j, m.Ax.dtype, flags)
-                self.blocks.append((pl, v, rows[b], rows[b + 1]))
-            self.plan = self.blocks[0][0]
-            self.sp, self.rank = sp, rank
+            self.fall_back(err)
+
+    def fall_back(self, err):
+        """Safety net so that a scaling run still measures something: the same row blocks through the C ABI's
+        block plans, the exchange through torch.distributed's RCCL group instead of the library's own."""
+        sp, rank, world, sub_blocks, rows, chunks, nnzs, shape, r0, Ap_l, Aj_l, Ax_l, flags = self._fb
+        m, kind = self.m, self.kind
+        if self.plan is not None:
+            self.plan.destroy()
+        sys.stderr.write("bench.py: the library's multi-GPU object failed (%s); exchanging y through torch.distributed\n" % err)
+        self.exchange = "FALLBACK torch.distributed over RCCL (the library's own communicator failed: %s)" % (err or "on another rank")
+        self.pg = dist.new_group(backend="nccl")
+        self.rank_cuts = [rows[r * sub_blocks] for r in range(world)] + [rows[-1]]
+        self.blocks = []
+        for b in range(rank * sub_blocks, (rank + 1) * sub_blocks):
+            a, j, v, _ = sp.dist.block_view(Ap_l, Aj_l, Ax_l, rows[b] - r0, rows[b + 1] - r0)
+            if rows[b + 1] == rows[b]:
+                continue
+            cb = chunks[b] if chunks is not None else 0
+            nc = (chunks[b + 1] - chunks[b]) if chunks is not None else 0
+            pl = sp.Plan.block(kind, shape, rows[b], cb, nc, nnzs[b], rows[b + 1] - rows[b], m.n_cols,
+                               int(a[-1].item()), a, j, m.Ax.dtype, flags)
+            self.blocks.append((pl, v, rows[b], rows[b + 1]))
+        self.plan = self.blocks[0][0]
+        self.sp, self.rank = sp, rank
+
+    def check_exchange(self, x, y):
+        """N > 1 only (cannot be rehearsed on the one-GPU test pool, so the run checks itself): one step on a y
+        poisoned with NaN; afterwards every rank must hold, for every rank's rows, the very bits their owner
+        holds (a checksum of the raw words per slice, compared over the gloo control plane), and no NaN.
+        A failed step or a mismatch anywhere sends every rank to the torch.distributed fallback, once."""
+        sp, rank, world, sub_blocks, rows = self._fb[:5]
+        cuts = [rows[r * sub_blocks] for r in range(world)] + [rows[-1]]
+        for attempt in range(2):
+            ok, err = 1, ""
+            try:
+                y.fill_(float("nan"))
+                self.execute(x, y)
+                torch.cuda.synchronize()
+                words = y.view(torch.int32 if y.element_size() == 4 else torch.int64)
+                sums = torch.stack([words[cuts[r]:cuts[r + 1]].to(torch.int64).sum() for r in range(world)]).cpu()
+                if bool(torch.isnan(y).any().item()):
+                    ok, err = 0, "rows left unwritten after the exchange"
+            except RuntimeError as e:
+                ok, err, sums = 0, str(e), torch.zeros(world, dtype=torch.int64)
+            box = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(box, sums)
+            if any(not torch.equal(b, box[0]) for b in box):
+                ok, err = 0, err or "a rank holds other bits than the owner of the rows"
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()):
+                return "bitwise equal on all ranks" + (" (after falling back)" if attempt else "")
+            if attempt or self.blocks is not None:
+                return "FAILED: " + (err or "on another rank")
+            self.fall_back(err)
+        return "FAILED"
 
     def execute(self, x, y):
         if self.blocks is None:
@@ -357,6 +395,7 @@ def main():
             runs[k] = Runner(sp, k, m, cuts, rank, world, sub_blocks, uid, flags, use_dist)
         n_rows_global = next(iter(runs.values())).n_rows_global
         y = torch.empty(n_rows_global, dtype=m.Ax.dtype, device=dev)
+        checks = {k: r.check_exchange(x, y) for k, r in runs.items()} if use_dist and (world > 1 or os.environ.get("MI355_BENCH_CHECK_EXCHANGE")) else {}   # (the knob: N = 1 rehearsal)
 
         # warm-up; with --kind auto the warm-up also picks the kind (outside the timed region)
         probe = {}
@@ -433,11 +472,13 @@ def main():
                                   (" (SpMV + exchange of this GPU)" if use_dist and world > 1 else "")},
             "warmup_probe_ms": probe,
         }
+        if checks:
+            out["exchange_check"] = checks[kind]
         if others:
             out["all_kinds"] = others
-        if not use_dist:
+        if world == 1:
             out["one_shot_ms"] = one_shot_ms(sp, kind, m, x, y)
-        if world == 1 and not use_dist and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, x, args.cpu_seconds)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
