@@ -48,6 +48,7 @@ static void parse_knobs(Knobs& k) {
     geti("MI355_SPMV_WINDOW", k.window);
     geti("MI355_SPMV_WINDOW_FROM_BAND", k.window_from_band);
     geti("MI355_SPMV_SEGMENTS", k.segments);
+    geti("MI355_SPMV_SWEEP", k.sweep);
     geti("MI355_SPMV_BALANCE", k.balance);
     geti("MI355_SPMV_LONG_STEPS", k.long_steps);
     geti("MI355_SPMV_GIANT", k.giant);
@@ -693,6 +694,45 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide, bool allow_huge)
             if (!(p.window_elems > 0 && p.n_seg < 2 && p.window_from_band)) p = saved;
         }
     }
+}
+
+// VECTOR, after decide_balance said "equal-row chunks" and no window of x was found: the band is wider than one
+// CU's LDS — let the window sweep it (chunk_rows_sweep).  A chunk is one group of rows of the 1 024-thread
+// workgroup, every row one step of its vector (T from the longest row the probe saw), and the chunk's band is
+// staged in `passes` windows.  Worth it while the staged bytes stay well below the line fills the same
+// nonzeros cost as plain gathers (128 bytes each, some of them L1 hits).  MI355_SPMV_SWEEP=0|1 forces the choice.
+bool shape_sweep(Plan& p) {
+    p.sweep = false;
+    if (p.balanced || p.knob.block > 0 || !p.probe_ok || p.window_elems != 0 || p.knob.window >= 0 ||
+        p.knob.rows_per_chunk > 0 || p.knob.sweep == 0 || p.probe_len_max <= 0 || p.probe_len_max > 4 * kWave)
+        return false;
+    const int64_t val_bytes = p.val_type == MI355_VAL_F64 ? 8 : 4;
+    const int64_t band = p.band_hi - p.band_lo + 1;
+    int t = p.lanes_per_row;
+    while (t < kWave && 4 * t < p.probe_len_max) t *= 2;
+    const int64_t rows = int64_t(kHugeBlock / t) * kSweepRows;
+    const int64_t fixed = int64_t(chunk_lds_bytes(0, int(rows), size_t(val_bytes)));
+    const int64_t cap = ((155 * 1024 - fixed) / val_bytes) & ~int64_t(3);
+    const int64_t span = band + rows + 8;
+    const int64_t passes = cap > 0 ? (span + cap - 1) / cap : 0;
+    const int64_t mean = p.n_rows > 0 ? (p.nnz - p.nnz_begin) / p.n_rows : 0;
+    const int64_t n_chunks = (p.n_rows + rows - 1) / rows;
+    const bool pays = span * val_bytes <= 64 * mean * rows;     // staged bytes vs half the gathers' line fills
+    if (!(band > 0 && passes >= 1 && passes <= 16 && n_chunks >= int64_t(kCus) * 2 && (pays || p.knob.sweep == 1))) return false;
+    p.sweep = true;
+    p.lanes_per_row = t;
+    p.block_threads = kHugeBlock;
+    p.rows_per_chunk = rows;
+    p.rows_cap = int(rows);
+    p.n_chunks = n_chunks;
+    p.grid_blocks = n_chunks;
+    p.n_tiles = n_chunks;
+    p.window_bytes = int(cap * val_bytes);
+    p.window_elems = int(cap);
+    p.window_from_band = true;
+    p.n_seg = 0;
+    snprintf(p.main_kernel, sizeof(p.main_kernel), "csr_vector_sweep_kernel");
+    return true;
 }
 
 // Rows per workgroup for which the plan's bands fit the window exactly:

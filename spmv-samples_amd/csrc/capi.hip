@@ -257,6 +257,7 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
         p.window_elems = w->window_elems;
         p.window_bytes = w->window_bytes;
         p.window_from_band = w->window_from_band != 0;
+        p.sweep = w->window_sweep != 0;
         p.n_seg = w->window_segments >= 2 ? w->window_segments : 0;
         p.probe_ok = w->probe_ok != 0;
         // (column - row) bands were measured with whole-matrix row numbers; this plan's rows start at 0
@@ -284,7 +285,7 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
         if (kind == MI355_KIND_VECTOR || kind == MI355_KIND_LIGHT) {
             const int st = decide_balance(p);    // heaviest uniform chunk vs the mean (synchronises)
             if (st != MI355_SPMV_OK) { delete h; return st; }
-            if (kind == MI355_KIND_VECTOR) reshape_vector_balanced(p);
+            if (kind == MI355_KIND_VECTOR) { reshape_vector_balanced(p); shape_sweep(p); }
             else reshape_light_balanced(p);
             const int st2 = find_giant_rows(p);  // balanced plans: rows too long for one workgroup (synchronises)
             if (st2 != MI355_SPMV_OK) { delete h; return st2; }
@@ -353,6 +354,7 @@ int mi355_spmv_plan_get_shape(const mi355_spmv_plan* h, mi355_spmv_plan_shape* s
     sh->bal_k = p.bal_k; sh->bal_q = p.bal_q; sh->giant_len = p.giant_len;
     sh->window_elems = p.window_elems; sh->window_bytes = p.window_bytes;
     sh->window_from_band = p.window_from_band ? 1 : 0;
+    sh->window_sweep = p.sweep ? 1 : 0;
     sh->window_segments = p.n_seg >= 2 ? p.n_seg : (p.window_elems > 0 ? 1 : 0);
     sh->probe_ok = p.probe_ok ? 1 : 0;
     sh->long_steps = p.knob.long_steps;

@@ -18,6 +18,7 @@ constexpr int64_t kGiantRow = 65536;   // a row beyond this many nonzeros is cut
 constexpr int64_t kGiantSlice = 32768;
 constexpr int kWideBlock = 512;      // VECTOR / LIGHT on big uniform matrices: 8 waves, chunks twice as long
 constexpr int kHugeBlock = 1024;     // VECTOR, band too wide for two workgroups per CU: ONE 16-wave workgroup with ~150 KB of LDS
+constexpr int kSweepRows = 4;        // rows a vector of the sweep kernel holds (its whole chunk stays in registers)
 constexpr int kXcds = 8;             // XCDs per MI355X, each with a private L2
 constexpr int kCus = 256;            // compute units per MI355X
 
@@ -56,6 +57,7 @@ struct Knobs {
     int window = -1;           // MI355_SPMV_WINDOW           0 = never stage x in LDS, 1 = always
     int window_from_band = -1; // MI355_SPMV_WINDOW_FROM_BAND 0 = sample every chunk, 1 = place from the probe's band
     int segments = -1;         // MI355_SPMV_SEGMENTS         0 = no multi-band windows
+    int sweep = -1;            // MI355_SPMV_SWEEP            0 = never sweep a wide band with the window, 1 = whenever legal
     int balance = -1;          // MI355_SPMV_BALANCE          0 = equal-row chunks, 1 = weight-cut chunks
     int long_steps = 0;        // MI355_SPMV_LONG_STEPS       steps after which a row goes to the long-row pass
     int giant = -1;            // MI355_SPMV_GIANT            0 = no giant-row slices
@@ -113,6 +115,7 @@ struct Plan {
     int window_bytes;           // LDS budget of the x window per workgroup (pick_window_elems)
     int window_elems;           // LDS window of x per workgroup, in elements; 0 = no window
     bool window_from_band;      // place the window from band_lo/band_hi instead of sampling per chunk
+    bool sweep = false;         // VECTOR: the band is wider than any window — one group of rows per chunk, the window sweeps the band (chunk_rows_sweep)
     // multi-band plan: up to 4 bands of (column - row) found by clustering the probe's samples
     int n_seg;
     int64_t seg_lo[4], seg_hi[4];
@@ -165,7 +168,8 @@ int merge_compute_coords(Plan& p);   // MERGE: run the search kernel now (null s
 int probe_structure(Plan& p);
 int pick_window_elems(Plan& p, int64_t rows_per_workgroup);
 int64_t segment_rows_fit(const Plan& p);
-void shape_chunks(Plan& p, int rows_in_flight, int64_t chunk_div, bool allow_wide, bool allow_huge = false);   // VECTOR / LIGHT: block size, chunk, window
+void shape_chunks(Plan& p, int rows_in_flight, int64_t chunk_div, bool allow_wide, bool allow_huge = false);
+bool shape_sweep(Plan& p);   // VECTOR: band wider than any window, after decide_balance (analyze.hip)   // VECTOR / LIGHT: block size, chunk, window
 int workgroups_per_cu_by_registers(const Plan& p);   // VECTOR / LIGHT: what the kernels' launch bounds allow
 int long_steps_for(const Plan& p);   // steps of its vector after which a row is left to the long-row pass
 int decide_balance(Plan& p);       // VECTOR / LIGHT, after shape_*: uniform or nnz-balanced chunks

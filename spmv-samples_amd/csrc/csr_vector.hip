@@ -80,6 +80,35 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= kWideBlock || R == 2 ? 4 : 3)) voi
     }
 }
 
+// The band is wider than any window of x: one 1 024-thread workgroup per CU, a chunk = one group of rows held in
+// registers, the window sweeps the band (xwindow.hpp, chunk_rows_sweep).
+template <int T, typename val_t>
+__global__ __launch_bounds__(kHugeBlock, 4) void csr_vector_sweep_kernel(
+    int32_t n_rows, int32_t n_cols, int64_t nnz, const ApView Ap, const int32_t* __restrict__ Aj,
+    const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, ChunkMap cmap,
+    int32_t window_cap, BandHint hint, val_t alpha, val_t beta) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
+    ChunkScratch<val_t> scr(s_dyn, window_cap, cmap.rows_cap);
+    scr.alpha = alpha;
+    scr.beta = beta;
+    const unsigned chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);   // (an XCD's chunks sweep neighbouring columns: its L2 holds them)
+    int64_t rb, re;
+    cmap.range(chunk, n_rows, rb, re);
+    if (rb >= re) return;
+    bool fits;
+    const int64_t base = stage_chunk_bounds<val_t>(scr, rb, re, Ap, cmap.rel_limit, fits);
+    if (!fits) {
+        chunk_rows_wide<kHugeBlock, val_t>(rb, re, Ap, Aj, Ax, x, y, alpha, beta, 0);
+        return;
+    }
+    __syncthreads();
+    const int64_t left = nnz - base;
+    const int32_t nnz_c = int32_t(left < kRel32Limit + 32768 ? left : kRel32Limit + 32768);
+    // (a persistent workgroup per CU walking its share of the chunks measured WORSE, 194 vs 187 us at two passes,
+    // 438 vs 358 at seven: the hardware dispatcher's refill costs less than the registers the loop does)
+    chunk_rows_sweep<kHugeBlock, T, kSweepRows, val_t>(rb, re, nnz_c, Aj + base, Ax + base, x, y, n_cols, window_cap, hint, scr);
+}
+
 template <int T, typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     int32_t n_rows, off_t nnz, const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj,
@@ -133,7 +162,7 @@ void reshape_vector_balanced(Plan& p) {
 void block_grid_vector(Plan& p) {
     p.grid_blocks = p.n_chunks;
     p.n_tiles = p.n_chunks;
-    snprintf(p.main_kernel, sizeof(p.main_kernel), "csr_vector_window_kernel");
+    snprintf(p.main_kernel, sizeof(p.main_kernel), p.sweep ? "csr_vector_sweep_kernel" : "csr_vector_window_kernel");
 }
 
 #endif  // MI355_TU_F64
@@ -204,6 +233,39 @@ static int launch_vector_window(const Plan& p, const ApView Ap, const val_t* Ax,
     return MI355_SPMV_OK;
 }
 
+template <typename val_t>
+static int launch_vector_sweep(const Plan& p, const ApView Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s) {
+    const BandHint hint{p.band_lo, p.band_hi, true};
+    const dim3 grid((unsigned)p.grid_blocks), block(kHugeBlock);
+    const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(val_t));
+    const ChunkMap cmap{nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, 0, int64_t(0),
+                        p.knob.rel32_limit > 0 ? p.knob.rel32_limit : kRel32Limit, 0};
+    if (p.rows_per_chunk != int64_t(kHugeBlock / p.lanes_per_row) * kSweepRows || p.rows_cap < p.rows_per_chunk) {
+        set_error("csr_vector: sweep plan with %lld rows per chunk at %d lanes per row", (long long)p.rows_per_chunk, p.lanes_per_row);
+        return MI355_SPMV_EINVAL;
+    }
+#define MI355_VEC_CASE(TT)                                                                                    \
+    case TT:                                                                                                  \
+        if (const int st = allow_dynamic_lds((const void*)csr_vector_sweep_kernel<TT, val_t>, lds)) return st; \
+        hipLaunchKernelGGL((csr_vector_sweep_kernel<TT, val_t>), grid, block, lds, s, p.n_rows, p.n_cols, p.nnz_read, Ap, \
+                           p.Aj, Ax, x, y, cmap, (int32_t)p.window_elems, hint, (val_t)p.alpha, (val_t)p.beta);   \
+        break;
+    switch (p.lanes_per_row) {
+        MI355_VEC_CASE(2)
+        MI355_VEC_CASE(4)
+        MI355_VEC_CASE(8)
+        MI355_VEC_CASE(16)
+        MI355_VEC_CASE(32)
+        MI355_VEC_CASE(64)
+        default:
+            set_error("csr_vector: bad lanes_per_row %d", p.lanes_per_row);
+            return MI355_SPMV_EINVAL;
+    }
+#undef MI355_VEC_CASE
+    MI355_HIP_TRY(hipGetLastError());
+    return MI355_SPMV_OK;
+}
+
 template <typename off_t, typename val_t>
 static int launch_vector_plain(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
                                hipStream_t s) {
@@ -241,6 +303,7 @@ int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* 
     const bool force_plain = p.knob.plain != 0 && !p.is_block;   // tuning / tests (a block keeps the whole plan's order)
     if (aligned && p.nnz >= 4 && !force_plain) {
         const ApView view{Ap, sizeof(off_t) == 8 ? 1 : 0};
+        if (p.sweep) return launch_vector_sweep<val_t>(p, view, Ax, x, y, s);
         return p.block_threads == kHugeBlock   ? launch_vector_window<kHugeBlock, val_t>(p, view, Ax, x, y, s)
                : p.block_threads == kWideBlock ? launch_vector_window<kWideBlock, val_t>(p, view, Ax, x, y, s)
                                                : launch_vector_window<kBlock, val_t>(p, view, Ax, x, y, s);

@@ -373,6 +373,37 @@ __device__ __forceinline__ void load_group(int32_t j, int32_t nnz, const int32_t
     }
 }
 
+// The chunk's results: one coalesced sweep from LDS (16-byte nontemporal stores when y is aligned);
+// y = alpha * sum + beta * y_old — y is read only when beta != 0 (alpha = 1, beta = 0: plain store).
+// The caller has put a barrier between the last write of s_y and this.
+template <int BLOCK, typename val_t>
+__device__ __forceinline__ void store_chunk_results(const ChunkScratch<val_t>& scr, val_t* __restrict__ y,
+                                                    int64_t chunk_begin, int rows) {
+    val_t* const yc = y + chunk_begin;
+    constexpr int PER16 = 16 / int(sizeof(val_t));
+    const val_t alpha = scr.alpha, beta = scr.beta;
+    const bool scaled = (alpha != val_t(1)) || (beta != val_t(0));   // uniform
+    const int n_store = scr.store_rows >= 0 ? scr.store_rows : rows;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // (opaque: keeps the sweep's per-thread offsets from being hoisted out of a persistent loop)
+    if (!scaled && (reinterpret_cast<uintptr_t>(yc) & 15u) == 0) {
+        using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
+        const int full = n_store / PER16;
+        for (int g = tid; g < full; g += BLOCK)
+            __builtin_nontemporal_store(*reinterpret_cast<const v16*>(scr.s_y + g * PER16),
+                                        reinterpret_cast<v16*>(yc + g * PER16));
+        for (int i = full * PER16 + tid; i < n_store; i += BLOCK) yc[i] = scr.s_y[i];
+    } else if (!scaled) {
+        for (int i = tid; i < n_store; i += BLOCK) yc[i] = scr.s_y[i];
+    } else {
+        for (int i = tid; i < n_store; i += BLOCK) {
+            val_t v = alpha * scr.s_y[i];
+            if (beta != val_t(0)) v += beta * yc[i];
+            yc[i] = v;
+        }
+    }
+}
+
 // Rows [chunk_begin, chunk_end) by this workgroup: T lanes per row, R rows per vector per
 // group, 4 nonzeros per lane per step.  Aj / Ax / nnz are CHUNK-RELATIVE (see stage_chunk_bounds).
 // Structure (each point is a measured win on the S32-band target, tools/exp_pipe.hip):
@@ -677,32 +708,8 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
         }
     }
 
-    // the chunk's results: one coalesced sweep (16-byte nontemporal stores when y is aligned);
-    // y = alpha * sum + beta * y_old — y is read only when beta != 0 (alpha = 1, beta = 0: plain store)
     __syncthreads();
-    val_t* const yc = y + chunk_begin;
-    constexpr int PER16 = 16 / int(sizeof(val_t));
-    const val_t alpha = scr.alpha, beta = scr.beta;
-    const bool scaled = (alpha != val_t(1)) || (beta != val_t(0));   // uniform
-    const int n_store = scr.store_rows >= 0 ? scr.store_rows : rows;
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));   // (opaque: keeps the sweep's per-thread offsets from being hoisted out of a persistent loop)
-    if (!scaled && (reinterpret_cast<uintptr_t>(yc) & 15u) == 0) {
-        using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
-        const int full = n_store / PER16;
-        for (int g = tid; g < full; g += BLOCK)
-            __builtin_nontemporal_store(*reinterpret_cast<const v16*>(scr.s_y + g * PER16),
-                                        reinterpret_cast<v16*>(yc + g * PER16));
-        for (int i = full * PER16 + tid; i < n_store; i += BLOCK) yc[i] = scr.s_y[i];
-    } else if (!scaled) {
-        for (int i = tid; i < n_store; i += BLOCK) yc[i] = scr.s_y[i];
-    } else {
-        for (int i = tid; i < n_store; i += BLOCK) {
-            val_t v = alpha * scr.s_y[i];
-            if (beta != val_t(0)) v += beta * yc[i];
-            yc[i] = v;
-        }
-    }
+    store_chunk_results<BLOCK, val_t>(scr, y, chunk_begin, rows);
 }
 
 // chunk_rows with the vector width chosen PER CHUNK (nnz-balanced plans): a power-law matrix has chunks of
@@ -724,6 +731,176 @@ __device__ __forceinline__ void chunk_rows_any(int64_t chunk_begin, int64_t chun
         else if (mean <= 64) chunk_rows<BLOCK, 8, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
         else chunk_rows<BLOCK, 32, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
     }
+}
+
+// 16-byte loads a thread of the sweep (chunk_rows_sweep) keeps in flight while a window is staged: a window of
+// ~9 600 groups is one batch in fp32, two in fp64 (whose body holds 32 more registers of Ax).
+__host__ __device__ constexpr int sweep_loads(size_t val_bytes) { return val_bytes == 4 ? 10 : 5; }
+
+// A band too wide for ANY window (more columns than a CU's LDS holds): the window SWEEPS the band.
+// The plain gather is bound by line fills — every lane of a gather instruction pulls its own 128-byte line
+// into the CU for 4 useful bytes (measured: ~96 cycles per 64-lane gather at a 131 K-column band) — while a
+// staged window moves whole lines at the same fill rate with every byte used.  So a chunk is exactly ONE group
+// of rows (BLOCK / T vectors x R rows: its step-0 loads of Aj / Ax stay in registers), the band of the chunk is
+// cut into windows of `cap` columns, and for every window in turn the workgroup stages it and each lane adds
+// the elements whose column falls inside.  Per chunk: BLOCK * R * 4 nonzero slots (2 MB of line fills as plain
+// gathers at 16 K slots) against passes * cap * sizeof(val_t) staged bytes — the plan takes this shape only
+// while the second is well below the first (analyze.hip, shape_chunks).
+// The band is the probe's (a sample): a column outside the swept span is gathered from global memory, a row
+// longer than one step (4 T nonzeros; the plan picks T from the longest row it saw) finishes with plain
+// gathers.  With sorted columns a lane adds its elements in the order chunk_rows does.
+// Same contract as chunk_rows: all BLOCK threads call, the caller has run stage_chunk_bounds + a barrier.
+template <int BLOCK, int T, int R, typename val_t>
+__device__ __forceinline__ void chunk_rows_sweep(int64_t chunk_begin, int64_t chunk_end, int32_t nnz,
+                                                 const int32_t* __restrict__ Aj, const val_t* __restrict__ Ax,
+                                                 const val_t* __restrict__ x, val_t* __restrict__ y,
+                                                 int32_t n_cols, int32_t cap, const BandHint hint,
+                                                 const ChunkScratch<val_t>& scr) {
+    using v4 = typename Vec4<val_t>::type;
+    using off_t = int32_t;
+    using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
+    constexpr int PER16 = 16 / int(sizeof(val_t));
+    constexpr int VW = kWave / T;
+    constexpr int SWEEP_LOADS = sweep_loads(sizeof(val_t));
+    // (opaque copy of the thread index: inside the kernel's loop over chunks the optimiser otherwise hoists every
+    // per-thread value below out of the loop, keeps them all live across the chunk and spills)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & (T - 1);
+    const int rows = int(chunk_end - chunk_begin);          // <= BLOCK / T * R (the plan's rows per chunk)
+    const off_t nnz_vec = nnz & ~off_t(3);
+    const off_t j_max = nnz_vec - 4;
+    const int row_in_wave = (tid & (kWave - 1)) / T;
+    const int wave_rows0 = (tid / kWave) * (VW * R);
+    auto row_of = [&](int r) { return wave_rows0 + r * VW + row_in_wave; };   // (chunk_rows' mapping, group 0)
+
+    int4v c[R];
+    v4 a[R];
+    val_t sum[R];
+    unsigned valid = 0;                                      // bit r * 4 + e: element e of slot r belongs to the row
+    // (the row bounds are read from LDS again after the sweep instead of being held in registers across it)
+    auto bounds = [&](int r, off_t& lo, off_t& hi, off_t& j) {
+        const int row = row_of(r);
+        lo = scr.s_b[min(row, rows)];
+        hi = scr.s_b[min(row + 1, rows)];
+        j = (lo & ~off_t(3)) + off_t(lane) * 4;
+    };
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        off_t lo, hi, j;
+        bounds(r, lo, hi, j);
+        off_t jl = j < hi ? j : (lo & ~off_t(3));
+        jl = jl < j_max ? jl : j_max;
+        c[r] = stream_load(reinterpret_cast<const int4v*>(Aj + jl));
+        a[r] = stream_load(reinterpret_cast<const v4*>(Ax + jl));
+        const off_t top = hi < nnz_vec ? hi : nnz_vec;       // (the arrays' last, partial group: scalar, below)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool mine = j + e >= lo && j + e < top;
+            if (mine) valid |= 1u << (r * 4 + e);
+            c[r][e] = mine ? c[r][e] : INT32_MAX;            // (a column no window holds: the sweep needs no second test)
+        }
+        sum[r] = val_t(0);
+    }
+
+    // the columns the chunk's rows may hold according to the plan's band, whole 16-byte groups of x
+    int64_t l = chunk_begin + hint.lo, h = chunk_end - 1 + hint.hi;
+    l = l < 0 ? 0 : l;
+    h = h >= n_cols ? int64_t(n_cols) - 1 : h;
+    const int c_lo = int(l) & ~(PER16 - 1), c_hi = int(h);    // (h < l: an empty sweep, everything falls to the gathers)
+    // Staging: SWEEP_LOADS 16-byte loads in flight per thread, straight-line (a conditional load makes hipcc wait for
+    // every load before the next, s_waitcnt vmcnt(0) at each branch): a group index past the window's end wraps
+    // to its first groups, which are loaded and stored a second time (same bytes, DISTINCT LDS addresses: clamping
+    // them all to the last group makes every lane of a wave store to one address).
+    // (Tried and dropped: the loads of window p + 1 issued before window p is consumed and held in registers
+    // meanwhile — 203 vs 190 us at two passes, 432 vs 370 at seven; a persistent workgroup per CU walking its share
+    // of the chunks — 194 vs 187, 438 vs 358.)
+    for (int w0 = c_lo; w0 <= c_hi; w0 += cap) {               // uniform over the workgroup; cap is a multiple of PER16
+        const int len = min(cap, c_hi + 1 - w0);
+        int full = (min(w0 + len, n_cols & ~(PER16 - 1)) - w0) / PER16;   // whole 16-byte groups of the window inside x
+        full = full > 0 ? full : 0;
+        if (w0 != c_lo) __syncthreads();                       // the previous window is still being read
+        for (int g0 = 0; g0 < full; g0 += SWEEP_LOADS * BLOCK) {   // uniform; the plan's window: one or two batches
+            v16 t[SWEEP_LOADS];
+            int gi[SWEEP_LOADS];
+#pragma unroll
+            for (int u = 0; u < SWEEP_LOADS; ++u) {
+                int g = g0 + u * BLOCK + tid;
+                g = g < full ? g : g - full;
+                gi[u] = min(g, full - 1);                      // (a window shorter than one batch)
+                t[u] = *reinterpret_cast<const v16*>(x + w0 + gi[u] * PER16);
+            }
+#pragma unroll
+            for (int u = 0; u < SWEEP_LOADS; ++u) *reinterpret_cast<v16*>(scr.s_x + gi[u] * PER16) = t[u];
+        }
+        for (int i = full * PER16 + tid; i < len; i += BLOCK) scr.s_x[i] = x[w0 + i];   // (the last columns of x)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            val_t xv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned rel = unsigned(c[r][e] - w0);
+                xv[e] = scr.s_x[rel < unsigned(len) ? rel : 0u];
+            }
+            // (the four values go through an empty volatile asm, i.e. the reads happen whatever the comparison says:
+            // left alone, hipcc turns the selects below into a branch per element — ds_read, wait, fma under
+            // s_cbranch_execz, sixteen times in a row)
+            asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool in = unsigned(c[r][e] - w0) < unsigned(len);
+                sum[r] = in ? (sum[r] + a[r][e] * xv[e]) : sum[r];
+            }
+        }
+    }
+    // what the probe's sample of the band missed: columns outside the swept span
+    {
+        bool any = false;
+        unsigned out = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (((valid >> (r * 4 + e)) & 1u) && (c[r][e] < c_lo || c[r][e] > c_hi)) { out |= 1u << (r * 4 + e); any = true; }
+        if (any) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((out >> (r * 4 + e)) & 1u) sum[r] += a[r][e] * x[c[r][e]];
+        }
+    }
+    // ... and rows longer than one step: the remaining steps with plain gathers
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        off_t lo, hi, j;
+        bounds(r, lo, hi, j);
+        const off_t top = hi < nnz_vec ? hi : nnz_vec;
+        for (off_t jj = j + off_t(T) * 4; jj < top; jj += off_t(T) * 4) {
+            const off_t jl = jj < j_max ? jj : j_max;           // (jj < top <= nnz_vec: jl == jj)
+            const int4v c2 = stream_load(reinterpret_cast<const int4v*>(Aj + jl));
+            const v4 a2 = stream_load(reinterpret_cast<const v4*>(Ax + jl));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (jj + e < top) sum[r] += a2[e] * x[c2[e]];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) sum[r] = vector_reduce<T, val_t>(sum[r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row_of(r);
+            if (row >= rows) continue;
+            const off_t lo = scr.s_b[row], hi = scr.s_b[row + 1];
+            if (hi > nnz_vec)                                  // the last (partial) group of the arrays
+                for (off_t k = (lo > nnz_vec ? lo : nnz_vec); k < hi; ++k) sum[r] += Ax[k] * x[Aj[k]];
+            scr.s_y[row] = sum[r];
+        }
+    }
+    __syncthreads();
+    store_chunk_results<BLOCK, val_t>(scr, y, chunk_begin, rows);
 }
 
 // A chunk whose nonzeros span more than the 32-bit path can index (see kRel32Limit): one wave per row,

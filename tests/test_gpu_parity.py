@@ -459,6 +459,68 @@ def test_wide_band_fp64_takes_more_than_64_kb_of_lds(sp, oracle, kind):
     assert_parity(oracle, Ap, Aj, Ax, x.cpu().numpy(), y.cpu().numpy())
 
 
+@pytest.mark.parametrize("off,val", [("i32", "f32"), ("i64", "f64")])
+def test_band_wider_than_any_window_is_swept(sp, oracle, off, val):
+    """A band of ~80 K columns (fp64: ~40 K) is more than ONE CU's LDS holds: the vector kind then makes a chunk one group
+    of rows held in registers and lets the window sweep the band (csr_vector_sweep_kernel; plain gathers ran at
+    1.6-2.4 TB/s).  The plan's band and longest row come from a SAMPLE of 256 rows, so the matrix also holds what the
+    sample cannot see: rows of 200 nonzeros (more than one step of their vector: the plain-gather tail), columns far
+    outside the band (gathered from global memory), an empty row, a short last chunk.  Every row against the oracle
+    bound; row blocks of the same plan must reproduce the whole result bit for bit."""
+    rng = np.random.default_rng(31)
+    n, per_row = 300_003, 32
+    hw = 40_000 if val == "f32" else 20_000
+    lens = np.full(n, per_row, dtype=np.int64)
+    probed = set(((n - 1) * np.arange(256)) // 255)
+    special = [r for r in (5, 1001, 150_001, n - 2) if r not in probed]
+    lens[special] = 200
+    lens[7] = 0
+    Ap = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=Ap[1:])
+    nnz = int(Ap[-1])
+    rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+    lo = np.clip(rows - hw, 0, n - 1)
+    hi = np.clip(rows + hw, 0, n - 1)
+    cols = lo + (rng.random(nnz) * (hi - lo + 1)).astype(np.int64)
+    far = [r for r in (9, 2000, 250_000) if r not in probed]
+    for r in far:                                       # first / last element of the row far outside the band
+        cols[Ap[r]] = 0 if r > n // 2 else n - 1
+        cols[Ap[r + 1] - 1] = n - 1 if r > n // 2 else 0
+    order = np.lexsort((cols, rows))                    # sorted columns inside each row (duplicates allowed: they add up)
+    Aj = cols[order].astype(np.int32)
+    Ax = (rng.random(nnz) - 0.5).astype(NP[val])
+    x = seeded_x(n, NP[val])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    dAp, dAj, dAx, dx = d(Ap.astype(NP[off])), d(Aj), d(Ax), d(x)
+    p = sp.Plan("vector", n, n, nnz, dAp, dAj, dAx.dtype)
+    info = p.info()
+    forced = any(k.startswith("MI355_SPMV_") for k in os.environ if k != "MI355_SPMV_LIB")
+    if not forced:
+        assert info["main_kernel"] == "csr_vector_sweep_kernel" and info["block_threads"] == 1024, info
+    y = torch.full((n,), float("nan"), dtype=dAx.dtype, device=DEV)
+    p.execute(dAx, dx, y)
+    torch.cuda.synchronize()
+    assert_parity(oracle, Ap.astype(NP[off]), Aj, Ax, x, y.cpu().numpy())
+    # the same plan cut into three row blocks: bit-identical rows
+    shape = p.shape()
+    row_cuts, chunk_cuts, nnz_cuts = p.partition(3)
+    y_blocks = torch.full((n,), float("nan"), dtype=dAx.dtype, device=DEV)
+    for b in range(3):
+        r0, r1 = row_cuts[b], row_cuts[b + 1]
+        if r1 == r0:
+            continue
+        a, j, v, _ = sp.dist.block_view(dAp, dAj, dAx, r0, r1)
+        pb = sp.Plan.block("vector", shape, r0, chunk_cuts[b], chunk_cuts[b + 1] - chunk_cuts[b], nnz_cuts[b], r1 - r0, n,
+                           int(a[-1].item()), a, j, dAx.dtype)
+        if not forced:
+            assert pb.info()["main_kernel"] == "csr_vector_sweep_kernel"
+        pb.execute(v, dx, y_blocks[r0:r1])
+        torch.cuda.synchronize()
+        pb.destroy()
+    p.destroy()
+    assert torch.equal(y.view(torch.int32 if val == "f32" else torch.int64), y_blocks.view(torch.int32 if val == "f32" else torch.int64))
+
+
 # ---- BASELINE-sized inputs ---------------------------------------------------------------------
 
 @pytest.mark.parametrize("kind", KINDS)
