@@ -66,6 +66,9 @@ def parse():
                     choices=["s32-band", "s32-rand", "c2-cant", "c3-webgoogle", "c4-nlpkkt", "c5-rmat24"])
     ap.add_argument("--kind", default="auto", choices=("auto",) + KINDS)
     ap.add_argument("--rows-log2", type=int, default=22, help="rows per GPU of the s32 workloads (2^k)")
+    ap.add_argument("--band-half-width", type=int, default=4096,
+                    help="s32-band: columns within +-this of the diagonal (4096 = the north-star target; wider bands "
+                         "exercise the 1 024-thread and the sweeping-window plans)")
     ap.add_argument("--s32-offsets", choices=("i32", "i64"), default="i32", help="offset type of the s32 workloads")
     ap.add_argument("--s32-values", choices=("f32", "f64"), default="f32", help="value type of the s32 workloads")
     ap.add_argument("--reuse-structure", action="store_true",
@@ -113,11 +116,11 @@ def build_local(sp, args, rank, world, dev, sub_blocks):
         # weak scaling: every rank generates its own 2^k rows of a banded matrix with world * 2^k rows; the
         # blocks are statistically alike, every rank can write down everybody's cuts (32 nonzeros per row)
         n = 1 << args.rows_log2
-        hw = 4096 if args.workload == "s32-band" else None
+        hw = args.band_half_width if args.workload == "s32-band" else None
         m = sp.synth.banded_fixed(n, 32, hw, seed=1 + rank, device=dev, row_offset=rank * n, n_cols=world * n,
                                   val_dtype=torch.float64 if args.s32_values == "f64" else torch.float32,
                                   off_dtype=torch.int64 if args.s32_offsets == "i64" else torch.int32,
-                                  name="S32-band" if hw else "S32-rand")
+                                  name=("S32-band" if hw == 4096 else "S32-band(+-%d)" % hw) if hw else "S32-rand")
         sub = [(n * s // sub_blocks) & ~3 for s in range(sub_blocks)]
         rows = [r * n + o for r in range(world) for o in sub] + [world * n]
         return m, {"rows": rows, "chunks": None, "nnz": [32 * r for r in rows], "shape": None, "kind_shape": {}}

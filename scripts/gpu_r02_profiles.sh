@@ -30,10 +30,14 @@ trace c5_merge --workload c5-rmat24 --kind merge
 trace c5_vector --workload c5-rmat24 --kind vector
 trace c5_light --workload c5-rmat24 --kind light
 trace rand_vector --workload s32-rand --kind vector
+trace wide32k_vector --band-half-width 32768 --kind vector
+trace wide16k_vector --band-half-width 16384 --kind vector
 for k in vector light merge; do
   pmc s32_${k}_fetch FETCH_SIZE --kind $k
   pmc s32_${k}_write WRITE_SIZE --kind $k
 done
+pmc wide32k_vector_fetch FETCH_SIZE --band-half-width 32768 --kind vector
+pmc wide32k_vector_write WRITE_SIZE --band-half-width 32768 --kind vector
 pmc c4_vector_fetch FETCH_SIZE --workload c4-nlpkkt --kind vector
 pmc c4_vector_write WRITE_SIZE --workload c4-nlpkkt --kind vector
 pmc s32_merge_sq "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" --kind merge

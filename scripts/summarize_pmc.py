@@ -10,8 +10,9 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-KEYS = ("csr_vector_window_kernel", "csr_vector_kernel", "light_rows_window_kernel", "light_rows_kernel",
-        "merge_tile_kernel", "merge_search_kernel", "merge_fixup_kernel", "merge_small_kernel", "giant_")
+KEYS = ("csr_vector_window_kernel", "csr_vector_sweep_kernel", "csr_vector_kernel", "light_rows_window_kernel",
+        "light_rows_kernel", "merge_rows_kernel", "merge_tile_kernel", "merge_search_kernel", "merge_fixup_kernel",
+        "merge_small_kernel", "giant_")
 
 
 def short(name):
