@@ -37,15 +37,15 @@ for val in vals:
             want, yabs = orc.spmv_ref64(Ap, Aj, Ax, x.cpu().numpy(), 16)
             bound = (np.diff(Ap.astype(np.int64)) + 2) * (2.0 ** -24 if val == torch.float32 else 2.0 ** -53) * yabs
             out = []
-            for knob in ("0", "1", None):
-                p = plan_with(knob, "vector", m, val)
+            for knob, kind in (("0", "vector"), (None, "vector"), (None, "light")):
+                p = plan_with(knob, kind, m, val)
                 y.fill_(float("nan"))
                 us = timeit(p, m, x, y)
                 i = p.info()
                 err = np.abs(y.cpu().numpy().astype(np.float64) - want)
                 ok = bool((err <= bound).all())
-                out.append("%s %7.1f us %5.0f GB/s (%s T%d b%d w%d) %s" % ("sweep=" + str(knob), us, m.algorithmic_bytes() / us / 1e3,
-                           i["main_kernel"][11:16], i["lanes_per_row"], i["block_threads"], i["window_elems"], "ok" if ok else "WRONG max %.3g" % err.max()))
+                out.append("%s %7.1f us %5.0f GB/s (%s T%d b%d w%d) %s" % (kind[0] + " sweep=" + str(knob), us, m.algorithmic_bytes() / us / 1e3,
+                           i["main_kernel"].split("_")[2], i["lanes_per_row"], i["block_threads"], i["window_elems"], "ok" if ok else "WRONG max %.3g" % err.max()))
                 p.destroy()
             print("%s nnz/row %3d half-width %7d : %s" % ("f32" if val == torch.float32 else "f64", per_row, hw, " | ".join(out)), flush=True)
             del m, x, y

@@ -696,7 +696,7 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide, bool allow_huge)
     }
 }
 
-// VECTOR, after decide_balance said "equal-row chunks" and no window of x was found: the band is wider than one
+// VECTOR / LIGHT, after decide_balance said "equal-row chunks" and no window of x was found: the band is wider than one
 // CU's LDS — let the window sweep it (chunk_rows_sweep).  A chunk is one group of rows of the 1 024-thread
 // workgroup, every row one step of its vector (T from the longest row the probe saw), and the chunk's band is
 // staged in `passes` windows.  Worth it while the staged bytes stay well below the line fills the same
@@ -731,7 +731,7 @@ bool shape_sweep(Plan& p) {
     p.window_elems = int(cap);
     p.window_from_band = true;
     p.n_seg = 0;
-    snprintf(p.main_kernel, sizeof(p.main_kernel), "csr_vector_sweep_kernel");
+    snprintf(p.main_kernel, sizeof(p.main_kernel), p.kind == MI355_KIND_LIGHT ? "light_rows_sweep_kernel" : "csr_vector_sweep_kernel");
     return true;
 }
 

@@ -286,7 +286,7 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
             const int st = decide_balance(p);    // heaviest uniform chunk vs the mean (synchronises)
             if (st != MI355_SPMV_OK) { delete h; return st; }
             if (kind == MI355_KIND_VECTOR) { reshape_vector_balanced(p); shape_sweep(p); }
-            else reshape_light_balanced(p);
+            else { reshape_light_balanced(p); if (shape_sweep(p)) reshape_light_sweep(p); }
             const int st2 = find_giant_rows(p);  // balanced plans: rows too long for one workgroup (synchronises)
             if (st2 != MI355_SPMV_OK) { delete h; return st2; }
             if (p.n_giant > 0) p.n_kernels = 3;

@@ -169,7 +169,7 @@ int probe_structure(Plan& p);
 int pick_window_elems(Plan& p, int64_t rows_per_workgroup);
 int64_t segment_rows_fit(const Plan& p);
 void shape_chunks(Plan& p, int rows_in_flight, int64_t chunk_div, bool allow_wide, bool allow_huge = false);
-bool shape_sweep(Plan& p);   // VECTOR: band wider than any window, after decide_balance (analyze.hip)   // VECTOR / LIGHT: block size, chunk, window
+bool shape_sweep(Plan& p);   // VECTOR / LIGHT: band wider than any window, after decide_balance (analyze.hip)   // VECTOR / LIGHT: block size, chunk, window
 int workgroups_per_cu_by_registers(const Plan& p);   // VECTOR / LIGHT: what the kernels' launch bounds allow
 int long_steps_for(const Plan& p);   // steps of its vector after which a row is left to the long-row pass
 int decide_balance(Plan& p);       // VECTOR / LIGHT, after shape_*: uniform or nnz-balanced chunks
@@ -182,6 +182,7 @@ void reshape_vector_balanced(Plan& p);
 void reshape_light_balanced(Plan& p);
 void block_grid_vector(Plan& p);   // row-block plans: grid / names from the inherited shape and the block's n_chunks
 void block_grid_light(Plan& p);
+void reshape_light_sweep(Plan& p);   // LIGHT: after shape_sweep said yes
 // nnz-balanced cuts on the plan's chunk boundaries (analyze.hip; reads Ap on the device, synchronises)
 int partition_plan(const Plan& p, int parts, int64_t* row_cuts, int64_t* chunk_cuts, int64_t* nnz_cuts);
 

@@ -285,6 +285,54 @@ __global__ __launch_bounds__(kBlock) void light_rows_kernel(
     light_leave(counters);
 }
 
+// The band is wider than any window of x (xwindow.hpp, chunk_rows_sweep; csr_vector.hip has the static twin): one
+// 1 024-thread workgroup per CU, a chunk = one group of rows held in registers, handed out by the counters exactly
+// as the equal-row chunks of light_rows_window_kernel are (one dequeue per workgroup).
+template <int T, typename val_t>
+__global__ __launch_bounds__(kHugeBlock, 4) void light_rows_sweep_kernel(
+    int32_t n_rows, int32_t n_cols, int64_t nnz, const ApView Ap, const int32_t* __restrict__ Aj,
+    const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
+    unsigned long long* __restrict__ counters, ChunkMap cmap, int32_t window_cap, BandHint hint, val_t alpha, val_t beta) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
+    __shared__ unsigned long long s_got;
+    ChunkScratch<val_t> scr(s_dyn, window_cap, cmap.rows_cap);
+    scr.alpha = alpha;
+    scr.beta = beta;
+    const bool static_mode = cmap.n_chunks <= int64_t(gridDim.x) && !cmap.dequeue_once;
+    const int home = blockIdx.x % kXcds;
+    int64_t chunk = -1;
+    if (static_mode) {
+        chunk = xcd_contiguous_id(blockIdx.x, gridDim.x);
+        if (chunk >= cmap.n_chunks) chunk = -1;
+    } else {
+        for (int visit = 0; visit < kXcds && chunk < 0; ++visit) {   // (uniform over the workgroup)
+            const int shard = (home + visit) % kXcds;
+            const int64_t shard_begin = cmap.n_chunks * shard / kXcds;
+            const int64_t shard_end = cmap.n_chunks * (shard + 1) / kXcds;
+            if (threadIdx.x == 0) s_got = atomicAdd(&counters[shard * kCounterStride], 1ull);
+            __syncthreads();
+            const int64_t c = shard_begin + int64_t(wave_broadcast_u64(s_got));
+            if (c < shard_end) chunk = c;
+            __syncthreads();
+        }
+    }
+    int64_t rb = 0, re = 0;
+    if (chunk >= 0) cmap.range(chunk, n_rows, rb, re);
+    if (rb < re) {
+        bool fits;
+        const int64_t base = stage_chunk_bounds<val_t>(scr, rb, re, Ap, cmap.rel_limit, fits);
+        if (!fits) {
+            chunk_rows_wide<kHugeBlock, val_t>(rb, re, Ap, Aj, Ax, x, y, alpha, beta, 0);
+        } else {
+            __syncthreads();
+            const int64_t left = nnz - base;
+            const int32_t nnz_c = int32_t(left < kRel32Limit + 32768 ? left : kRel32Limit + 32768);
+            chunk_rows_sweep<kHugeBlock, T, kSweepRows, val_t>(rb, re, nnz_c, Aj + base, Ax + base, x, y, n_cols, window_cap, hint, scr);
+        }
+    }
+    if (!static_mode) light_leave(counters);
+}
+
 template <typename val_t> constexpr int light_rows_in_flight() { return sizeof(val_t) == 4 ? 4 : 2; }
 
 #ifndef MI355_TU_F64   // the host-side shape functions live in the fp32 translation unit only
@@ -344,9 +392,16 @@ void reshape_light_balanced(Plan& p) {
 
 void block_grid_light(Plan& p) {
     p.n_tiles = p.n_chunks;
-    p.grid_blocks = light_grid(p, p.n_chunks, light_resident(p, p.balanced ? p.rows_cap : p.rows_per_chunk));
-    p.light_dequeue_once = light_dequeue_once(p, p.n_chunks, light_resident(p, p.balanced ? p.rows_cap : p.rows_per_chunk));
-    snprintf(p.main_kernel, sizeof(p.main_kernel), "light_rows_window_kernel");
+    const int64_t resident = p.sweep ? int64_t(kCus) : light_resident(p, p.balanced ? p.rows_cap : p.rows_per_chunk);
+    p.grid_blocks = light_grid(p, p.n_chunks, resident);
+    p.light_dequeue_once = light_dequeue_once(p, p.n_chunks, resident);
+    snprintf(p.main_kernel, sizeof(p.main_kernel), p.sweep ? "light_rows_sweep_kernel" : "light_rows_window_kernel");
+}
+
+// after shape_sweep said yes (analyze.hip): one workgroup per chunk, one per CU resident
+void reshape_light_sweep(Plan& p) {
+    if (!p.sweep) return;
+    block_grid_light(p);
 }
 
 #endif  // MI355_TU_F64
@@ -416,6 +471,39 @@ static int launch_light_window(const Plan& p, const ApView Ap, const val_t* Ax, 
     return MI355_SPMV_OK;
 }
 
+template <typename val_t>
+static int launch_light_sweep(const Plan& p, const ApView Ap, const val_t* Ax, const val_t* x, val_t* y, hipStream_t s) {
+    const BandHint hint{p.band_lo, p.band_hi, true};
+    const dim3 grid((unsigned)p.grid_blocks), block(kHugeBlock);
+    const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(val_t));
+    const ChunkMap cmap{nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, 0, int64_t(0),
+                        p.knob.rel32_limit > 0 ? p.knob.rel32_limit : kRel32Limit, p.light_dequeue_once ? 1 : 0};
+    if (p.rows_per_chunk != int64_t(kHugeBlock / p.lanes_per_row) * kSweepRows || p.rows_cap < p.rows_per_chunk) {
+        set_error("light_rows: sweep plan with %lld rows per chunk at %d lanes per row", (long long)p.rows_per_chunk, p.lanes_per_row);
+        return MI355_SPMV_EINVAL;
+    }
+#define MI355_LIGHT_CASE(TT)                                                                                   \
+    case TT:                                                                                                   \
+        if (const int st = allow_dynamic_lds((const void*)light_rows_sweep_kernel<TT, val_t>, lds)) return st; \
+        hipLaunchKernelGGL((light_rows_sweep_kernel<TT, val_t>), grid, block, lds, s, p.n_rows, p.n_cols, p.nnz_read, Ap, \
+                           p.Aj, Ax, x, y, p.counters, cmap, (int32_t)p.window_elems, hint, (val_t)p.alpha, (val_t)p.beta); \
+        break;
+    switch (p.lanes_per_row) {
+        MI355_LIGHT_CASE(2)
+        MI355_LIGHT_CASE(4)
+        MI355_LIGHT_CASE(8)
+        MI355_LIGHT_CASE(16)
+        MI355_LIGHT_CASE(32)
+        MI355_LIGHT_CASE(64)
+        default:
+            set_error("light_rows: bad lanes_per_row %d", p.lanes_per_row);
+            return MI355_SPMV_EINVAL;
+    }
+#undef MI355_LIGHT_CASE
+    MI355_HIP_TRY(hipGetLastError());
+    return MI355_SPMV_OK;
+}
+
 template <typename off_t, typename val_t>
 static int launch_light_plain(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x, val_t* y,
                               hipStream_t s) {
@@ -450,6 +538,7 @@ int launch_light(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* x
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
     if (aligned && p.nnz >= 4) {
         const ApView view{Ap, sizeof(off_t) == 8 ? 1 : 0};
+        if (p.sweep) return launch_light_sweep<val_t>(p, view, Ax, x, y, s);
         return p.block_threads == kHugeBlock   ? launch_light_window<kHugeBlock, val_t>(p, view, Ax, x, y, s)
                : p.block_threads == kWideBlock ? launch_light_window<kWideBlock, val_t>(p, view, Ax, x, y, s)
                                                : launch_light_window<kBlock, val_t>(p, view, Ax, x, y, s);

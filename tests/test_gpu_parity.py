@@ -459,10 +459,11 @@ def test_wide_band_fp64_takes_more_than_64_kb_of_lds(sp, oracle, kind):
     assert_parity(oracle, Ap, Aj, Ax, x.cpu().numpy(), y.cpu().numpy())
 
 
+@pytest.mark.parametrize("kind", ["vector", "light"])
 @pytest.mark.parametrize("off,val", [("i32", "f32"), ("i64", "f64")])
-def test_band_wider_than_any_window_is_swept(sp, oracle, off, val):
+def test_band_wider_than_any_window_is_swept(sp, oracle, off, val, kind):
     """A band of ~80 K columns (fp64: ~40 K) is more than ONE CU's LDS holds: the vector kind then makes a chunk one group
-    of rows held in registers and lets the window sweep the band (csr_vector_sweep_kernel; plain gathers ran at
+    of rows held in registers and lets the window sweep the band (csr_vector_sweep_kernel / light_rows_sweep_kernel; plain gathers ran at
     1.6-2.4 TB/s).  The plan's band and longest row come from a SAMPLE of 256 rows, so the matrix also holds what the
     sample cannot see: rows of 200 nonzeros (more than one step of their vector: the plain-gather tail), columns far
     outside the band (gathered from global memory), an empty row, a short last chunk.  Every row against the oracle
@@ -492,11 +493,12 @@ def test_band_wider_than_any_window_is_swept(sp, oracle, off, val):
     x = seeded_x(n, NP[val])
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
     dAp, dAj, dAx, dx = d(Ap.astype(NP[off])), d(Aj), d(Ax), d(x)
-    p = sp.Plan("vector", n, n, nnz, dAp, dAj, dAx.dtype)
+    sweep_kernel = "csr_vector_sweep_kernel" if kind == "vector" else "light_rows_sweep_kernel"
+    p = sp.Plan(kind, n, n, nnz, dAp, dAj, dAx.dtype)
     info = p.info()
-    forced = any(k.startswith("MI355_SPMV_") for k in os.environ if k != "MI355_SPMV_LIB")
+    forced = any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB")
     if not forced:
-        assert info["main_kernel"] == "csr_vector_sweep_kernel" and info["block_threads"] == 1024, info
+        assert info["main_kernel"] == sweep_kernel and info["block_threads"] == 1024, info
     y = torch.full((n,), float("nan"), dtype=dAx.dtype, device=DEV)
     p.execute(dAx, dx, y)
     torch.cuda.synchronize()
@@ -510,10 +512,10 @@ def test_band_wider_than_any_window_is_swept(sp, oracle, off, val):
         if r1 == r0:
             continue
         a, j, v, _ = sp.dist.block_view(dAp, dAj, dAx, r0, r1)
-        pb = sp.Plan.block("vector", shape, r0, chunk_cuts[b], chunk_cuts[b + 1] - chunk_cuts[b], nnz_cuts[b], r1 - r0, n,
+        pb = sp.Plan.block(kind, shape, r0, chunk_cuts[b], chunk_cuts[b + 1] - chunk_cuts[b], nnz_cuts[b], r1 - r0, n,
                            int(a[-1].item()), a, j, dAx.dtype)
         if not forced:
-            assert pb.info()["main_kernel"] == "csr_vector_sweep_kernel"
+            assert pb.info()["main_kernel"] == sweep_kernel
         pb.execute(v, dx, y_blocks[r0:r1])
         torch.cuda.synchronize()
         pb.destroy()
