@@ -503,6 +503,16 @@ def test_band_wider_than_any_window_is_swept(sp, oracle, off, val, kind):
     p.execute(dAx, dx, y)
     torch.cuda.synchronize()
     assert_parity(oracle, Ap.astype(NP[off]), Aj, Ax, x, y.cpu().numpy())
+    # y = alpha * A x + beta * y_old through the same kernel: against the plain result, two roundings per row
+    y_old = torch.from_numpy(seeded_x(n, NP[val])).to(DEV) * 0.5
+    y_ab = y_old.clone()
+    p.set_alpha_beta(-0.75, 3.0)
+    p.execute(dAx, dx, y_ab)
+    torch.cuda.synchronize()
+    p.set_alpha_beta(1.0, 0.0)
+    want_ab = -0.75 * y.double() + 3.0 * y_old.double()
+    eps = 2.0 ** -23 if val == "f32" else 2.0 ** -52
+    assert bool(((y_ab.double() - want_ab).abs() <= 2 * eps * (0.75 * y.double().abs() + 3.0 * y_old.double().abs()) + 1e-300).all())
     # the same plan cut into three row blocks: bit-identical rows
     shape = p.shape()
     row_cuts, chunk_cuts, nnz_cuts = p.partition(3)
