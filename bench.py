@@ -25,8 +25,9 @@ be timed with --workload.
 
 One JSON line on stdout (rank 0).  Extra objects:
   roofline      achieved = ALGORITHMIC bytes of one SpMV / mean device time of one
-                execute, from HIP events recorded on the launch stream around every
-                timed step; peak = 8000 GB/s (HBM3E spec, MI355X_MICROARCH.md);
+                execute = (HIP events recorded on the launch stream around the K timed
+                executes) / K; min / median from a second pass with events around every
+                execute; peak = 8000 GB/s (HBM3E spec, MI355X_MICROARCH.md);
                 traffic = HBM bytes per launch from rocprofv3 PMC passes (read from
                 profiles/, null if that file is absent)
   cpu_baseline  the reference's serial CPU SpMV (cpu_navie.hpp:5-17) timed on this
@@ -257,30 +258,40 @@ class Runner:
 _FLUSH = {"buf": None}
 
 
-def time_steps(run, x, y, use_dist, steps):
-    """K steps; returns (wall seconds between the two syncs, list of device ms of every execute).
-    A step of the multi-GPU path is complete when this GPU holds the WHOLE y (the library makes the
-    caller's stream wait for its communication stream), so the HIP events bracket SpMV + exchange there."""
-    # HIP events bracket EVERY timed execute.  A pair costs the stream ~6 us of wall per step (184.1 vs 178.8 us
-    # with a pair on every 6th step), but sampled pairs read the bracketed execute 2-5 % too long (the marker
-    # before it is then not back to back with the one after the previous execute), and the kernel time is
-    # what the roofline fraction is computed from: the rocprofv3 trace agrees with the per-step pairs.
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+def time_steps(run, x, y, use_dist, steps, per_step=False):
+    """K steps; returns (wall seconds between the two syncs, list of device ms).
+    per_step=False (the timed region): ONE pair of HIP events around the K executes, on the stream they are
+    launched on — the list holds their mean, K times.  per_step=True (a separate, instrumented pass; always in
+    --cold mode): a pair around EVERY execute, for the minimum / median — each pair costs the stream ~6 us of wall
+    per step (184.1 vs 178.8 us), which is why the timed region does not carry them.
+    A step of the multi-GPU path is complete when this GPU holds the WHOLE y (the library makes the caller's stream
+    wait for its communication stream), so the events bracket SpMV + exchange there."""
+    per_step = per_step or _FLUSH["buf"] is not None
+    n_ev = steps if per_step else 1
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if not per_step:
+        evs[0][0].record()
     for i in range(steps):
         if _FLUSH["buf"] is not None:
             _FLUSH["buf"].fill_(float(i))      # cold mode: evict the matrix from L2 / Infinity Cache
-        evs[i][0].record()
+        if per_step:
+            evs[i][0].record()
         run.execute(x, y)
-        evs[i][1].record()
+        if per_step:
+            evs[i][1].record()
+    if not per_step:
+        evs[0][1].record()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     wall = time.perf_counter() - t0
-    return wall, [a.elapsed_time(b) for a, b in evs]
+    if per_step:
+        return wall, [a.elapsed_time(b) for a, b in evs]
+    return wall, [evs[0][0].elapsed_time(evs[0][1]) / steps] * steps
 
 
 def one_shot_ms(sp, kind, m, x, y, reps=5):
@@ -415,8 +426,9 @@ def main():
         kind = KINDS[int(torch.argmin(best).item())]
     run = runs[kind]
 
-    wall, dev_list = time_steps(run, x, y, use_dist, args.steps)
+    wall, dev_list = time_steps(run, x, y, use_dist, args.steps)            # THE timed region
     dev_ms = float(np.mean(dev_list))
+    _, step_list = time_steps(run, x, y, use_dist, args.steps, per_step=True)   # instrumented pass: spread of single executes
     tmax = torch.tensor([wall], dtype=torch.float64)
     nnz_all = torch.tensor([float(run.nnz_local)], dtype=torch.float64)
     if use_dist:
@@ -469,9 +481,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": info["main_kernel"], "kernel_ms": dev_ms,
-                         "kernel_ms_min": float(np.min(dev_list)), "kernel_ms_median": float(np.median(dev_list)),
+                         "kernel_ms_min": float(np.min(step_list)), "kernel_ms_median": float(np.median(step_list)),
+                         "kernel_ms_mean_instrumented": float(np.mean(step_list)),
                          "algorithmic_bytes": bytes_alg,
-                         "timed": "HIP events around every execute of the timed region" +
+                         "timed": ("kernel_ms = one pair of HIP events around the K executes of the timed region / K, on the "
+                                   "launch stream; min / median / mean_instrumented = a second pass of K executes with a "
+                                   "pair around each" if _FLUSH["buf"] is None else
+                                   "HIP events around every execute of the timed region (cold mode)") +
                                   (" (SpMV + exchange of this GPU)" if use_dist and world > 1 else "")},
             "warmup_probe_ms": probe,
         }
