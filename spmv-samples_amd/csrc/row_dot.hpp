@@ -31,7 +31,11 @@ template <> struct Vec4<double> { using type = double4v; };
 // read pattern of the kernels: 6.9 TB/s nontemporal vs 6.15 TB/s plain.
 template <typename V>
 __device__ __forceinline__ V stream_load(const V* p) {
+#ifdef MI355_STREAM_PLAIN   // (A/B builds only)
+    return *p;
+#else
     return __builtin_nontemporal_load(p);
+#endif
 }
 
 // 4-byte-per-lane partial sum of lane `lane` (0..T-1) of the vector that owns [start, end):
