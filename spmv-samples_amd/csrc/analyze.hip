@@ -590,6 +590,7 @@ static int window_budget(const Plan& p, int block_threads, int64_t rows) {
 // fits a CU and it lost, 237 us).
 void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide, bool allow_huge) {
     if (p.val_type == MI355_VAL_F32 && p.lanes_per_row >= 16 && R > 2) R = 2;   // (the kernels' rule: launch_*_window, wide_r)
+    int64_t rows_before_rounding = 0;        // of the last shape(): the chunk before it was shrunk to whole rounds
     auto shape = [&](int block_threads, int64_t nnz_per_chunk) {
         p.block_threads = block_threads;
         const int64_t pass = int64_t(block_threads / p.lanes_per_row) * R;
@@ -603,6 +604,7 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide, bool allow_huge)
         }
         if (rows < pass) rows = pass;
         p.rows_per_chunk = rows;
+        rows_before_rounding = rows;
         p.window_bytes = window_budget(p, block_threads, rows);
         p.window_elems = pick_window_elems(p, rows);
         if (const int64_t fit = segment_rows_fit(p)) {   // several bands: shrink the chunk until they all fit
@@ -643,7 +645,10 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide, bool allow_huge)
         // keep it when (a) the ">= 4 chunks per CU" rule left the chunk long and (b) one window placed from the
         // band serves it (with 64-bit offsets / fp64 / several bands the 64 KB a launch may take is better spent
         // on three workgroups of 256: C4 stand-in 660 us vs 824 us)
-        const bool long_chunk = p.rows_per_chunk * mean >= 49152 || p.rows_per_chunk >= kMaxChunkRows;
+        // ("long" is judged before the chunk was shrunk to whole rounds: rows of 20-24 nonzeros reach the 2 048-row cap
+        // at 41-49 K nonzeros, were shrunk a little, then failed the 48 K test and fell to 256 threads — 302 us against
+        // 245 / 201 for 18 / 26 per row on either side)
+        const bool long_chunk = p.rows_per_chunk * mean >= 49152 || rows_before_rounding >= kMaxChunkRows;
         // (a forced 512 is honoured unless the window needs several bands: those kernels exist for 256 threads only)
         if ((force && p.n_seg < 2) || (long_chunk && p.window_elems > 0 && p.n_seg < 2 && p.window_from_band)) return;
     }

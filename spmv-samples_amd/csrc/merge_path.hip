@@ -552,7 +552,7 @@ __global__ __launch_bounds__(BLOCK, 3) void merge_rows_kernel(
             return true;
         };
         auto stage = [&] { return stage_x_window<val_t>(rb, re, n_cols, first_last, x, scr.s_x, window_cap, s_red, hint); };
-        chunk_rows_any<BLOCK, 2, R, WINDOW, true, val_t>(rb, re, nnz_c, Aj_c, Ax_c, x, y, stage, scr);
+        chunk_rows_any<BLOCK, 2, R, WINDOW, true, val_t, decltype(stage)&, true>(rb, re, nnz_c, Aj_c, Ax_c, x, y, stage, scr);
         __syncthreads();
         if (pe == n_all && n_all > n_store_all) carry = uniform_val(scr.s_y[rows - 1]);   // (one LDS word: scalar register)
         __syncthreads();                                                       // ... read before the next piece refills it
@@ -597,16 +597,22 @@ static bool merge_search_in_kernel(const Plan& p) {
     return p.n_super <= int64_t(kCus) * 8;
 }
 
-// Row-parallel runs (merge_rows_kernel) for a matrix whose rows are alike and not short — the probe's 256 sampled rows
-// all hold between a quarter of and four times the mean, the mean is at least 8 — and big enough for runs of 16 K+ items
-// (on a small matrix a run is a tile or two: the window and the two diagonals cost more than they are worth — cant
-// stand-in 40.6 us against 19.5 with the item walk).  MI355_MERGE_ROWS = 0 | 1 overrides.
+// Row-parallel runs (merge_rows_kernel) for a matrix whose rows all but fill ONE step of a vector of 2, 8 or 32 lanes
+// (the widths the run body picks from: 8, 32, 128 nonzeros per step) — the probe's 256 sampled rows all hold between
+// three quarters of such a step and the whole of it — and big enough for runs of 16 K+ items (on a small matrix a run
+// is a tile or two: the window and the two diagonals cost more than they are worth — cant stand-in 40.6 us against 19.5
+// with the item walk).  Measured on 2^27 nonzeros (us, runs / item walk; scripts/gpu_r02_merge_regular.py): fixed 8 per
+// row 345 / 404, 27: 243 / 268, 32: 222 / 262, 100: 232 / 240, 128: 201 / 237 — but 12: 491 / 354, 16: 363 / 300,
+// 40: 411 / 258, 64: 282 / 251 (half the lanes idle, or a second dependent step), and rows of VARYING length lose
+// at every mean (24 +- 6: 397 / 326, 64 +- 16: 514 / 403, 128 +- 32: 489 / 380): those keep the item walk, which at
+// 5.0-5.4 TB/s is then also ahead of the CSR-vector kind.  MI355_MERGE_ROWS = 0 | 1 overrides.
 static bool merge_rows_wanted(const Plan& p) {
     if (p.knob.merge_rows >= 0) return p.knob.merge_rows != 0;
     if (!p.probe_ok || p.n_rows <= 0) return false;
     if (p.tiles_per_super * p.tile_items < 16384) return false;
-    const int64_t mean = (p.nnz - p.nnz_begin) / p.n_rows;
-    return mean >= 8 && p.probe_len_min * 4 >= mean && p.probe_len_max <= 4 * mean + 8;
+    for (const int64_t step : {8, 32, 128})
+        if (p.probe_len_max <= step && p.probe_len_min * 4 >= step * 3) return true;
+    return false;
 }
 
 void shape_merge(Plan& p) {
