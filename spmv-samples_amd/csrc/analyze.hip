@@ -667,8 +667,14 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide, bool allow_huge)
         int64_t rows = (78 * 1024 - val_bytes * (band + 8) - off_bytes) * 8 / (8 * (2 * val_bytes + off_bytes) + 1);
         rows = rows / pass * pass;
         if (rows > kMaxChunkRows) rows = kMaxChunkRows / pass * pass;
+        // (a matrix too small for a full round of such chunks takes shorter ones — the band still fits: 2^18 rows x 64
+        // in fp64 fell to the 1 024-thread plan at 3.9 TB/s for want of 512 chunks of 704 rows)
+        if (rows > 0 && (p.n_rows + rows - 1) / rows < int64_t(kCus) * 2) {
+            const int64_t fewer = ((int64_t(p.n_rows) + int64_t(kCus) * 2 - 1) / (int64_t(kCus) * 2) + pass - 1) / pass * pass;
+            if (fewer < rows) rows = fewer;
+        }
         const int64_t n_chunks = rows > 0 ? (p.n_rows + rows - 1) / rows : 0;
-        if (band > 0 && rows >= pass && rows >= 256 && n_chunks >= int64_t(kCus) * 2) {   // (>= one full round of the chip)
+        if (band > 0 && rows >= pass && rows >= 256 && n_chunks >= int64_t(kCus) * 2 - 8) {   // (>= one full round of the chip)
             const Plan saved = p;
             p.block_threads = kWideBlock;
             p.rows_per_chunk = rows;
