@@ -61,14 +61,19 @@ enum {
  *            include/spmv/LightSpMV.cuh:379-416)                              */
 enum { MI355_KIND_VECTOR = 0, MI355_KIND_MERGE = 1, MI355_KIND_LIGHT = 2, MI355_KIND_COUNT = 3 };
 enum { MI355_OFF_I32 = 0, MI355_OFF_I64 = 1 };
-enum { MI355_VAL_F32 = 0, MI355_VAL_F64 = 1 };
+enum { MI355_VAL_F32 = 0, MI355_VAL_F64 = 1,
+       /* 32-bit integers: the MERGE kind only (every semiring; two's-complement wrap-around, exact whatever the
+        * reduction order).  The reference's generalized merge kind is a template over the value types and its
+        * functor (merge_genl.cuh:19-38, :134-150); this is the integer / boolean instance of it.  VECTOR / LIGHT
+        * plans and alpha / beta return MI355_SPMV_ENOTSUP for it.                                              */
+       MI355_VAL_I32 = 2 };
 
 /* semirings of the generalized merge kind.  The reference's
  * SpMV_merge_based_generalized takes a functor_t with initialize / combine / reduce
  * (include/spmv/merge_genl/merge_genl.cuh:19-38; CPU twin include/spmv/cpu_navie.hpp:20-34)
  * and ships (+, *); a C ABI cannot take a C++ functor and enumerates them instead:
  *   PLUS_TIMES  y[r] = sum_k  Ax[k] * x[Aj[k]]           (identity 0)      — every other entry point
- *   MIN_PLUS    y[r] = min_k (Ax[k] + x[Aj[k]])          (identity +inf)   — shortest-path relaxation
+ *   MIN_PLUS    y[r] = min_k (Ax[k] + x[Aj[k]])          (identity +inf; INT32_MAX for integers) — shortest-path relaxation
  *   MAX_TIMES   y[r] = max_k (Ax[k] * x[Aj[k]])          (identity -inf)   — widest / most reliable path
  *   MAX_PLUS    y[r] = max_k (Ax[k] + x[Aj[k]])          (identity -inf)   — longest path, Viterbi
  *   OR_AND      y[r] = OR_k (Ax[k] != 0 AND x[Aj[k]] != 0) as 1.0 / 0.0  (identity 0)
@@ -116,6 +121,8 @@ MI355_SPMV_DECLARE_GENL(i32_f32, int32_t, float)
 MI355_SPMV_DECLARE_GENL(i32_f64, int32_t, double)
 MI355_SPMV_DECLARE_GENL(i64_f32, int64_t, float)
 MI355_SPMV_DECLARE_GENL(i64_f64, int64_t, double)
+MI355_SPMV_DECLARE_GENL(i32_i32, int32_t, int32_t)   /* integer values: identities 0 / INT32_MAX / INT32_MIN, OR_AND as 1 / 0 */
+MI355_SPMV_DECLARE_GENL(i64_i32, int64_t, int32_t)
 
 /* ---- plan entry points -----------------------------------------------------
  * The reference re-creates scratch on every call (quirks 7-9 of SURVEY.md §2c);

@@ -24,7 +24,7 @@ MTX_ERRORS = {0: "ok", 1: "open", 2: "banner", 3: "array", 4: "size", 5: "overfl
 
 def suffix(Ap, Ax):
     o = {np.dtype(np.int32): "i32", np.dtype(np.int64): "i64"}[np.asarray(Ap).dtype]
-    v = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[np.asarray(Ax).dtype]
+    v = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64", np.dtype(np.int32): "i32"}[np.asarray(Ax).dtype]
     return o, v
 
 
@@ -72,7 +72,8 @@ class Oracle:
         return y
 
     def spmv_genl_serial(self, semiring, Ap, Aj, Ax, x):
-        """Generalized serial SpMV (cpu_navie.hpp:20-34); semiring 0 = (+,*), 1 = (min,+), 2 = (max,*)."""
+        """Generalized serial SpMV (cpu_navie.hpp:20-34); semiring 0 = (+,*), 1 = (min,+), 2 = (max,*), 3 = (max,+),
+        4 = (or,and); Ax / x float32, float64 or int32."""
         n = self._check(Ap, Aj, Ax, x)
         o, v = suffix(Ap, Ax)
         y = np.empty(n, dtype=Ax.dtype)

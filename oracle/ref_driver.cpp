@@ -27,23 +27,32 @@ namespace {
 // The reference's only instance, MergeFunctor (merge_genl.cuh:19-38: initialize 0, combine
 // nonzero*x, reduce a+b), sits in a CUDA/CUB header and cannot be included; PlusTimes restates
 // its three one-liners, the other two are the semirings the C ABI adds.
+// (+-infinity of a value type: the extreme integers for int — numeric_limits<int>::infinity() is 0)
+template <typename V> struct Lim {
+    static V hi() { return std::numeric_limits<V>::infinity(); }
+    static V lo() { return -std::numeric_limits<V>::infinity(); }
+};
+template <> struct Lim<int> {
+    static int hi() { return std::numeric_limits<int>::max(); }
+    static int lo() { return std::numeric_limits<int>::lowest(); }
+};
 template <typename V> struct PlusTimes {
     static V initialize() { return V(0); }
     static V combine(V a, V x) { return a * x; }
     static V reduce(V u, V v) { return u + v; }
 };
 template <typename V> struct MinPlus {
-    static V initialize() { return std::numeric_limits<V>::infinity(); }
+    static V initialize() { return Lim<V>::hi(); }
     static V combine(V a, V x) { return a + x; }
     static V reduce(V u, V v) { return v < u ? v : u; }
 };
 template <typename V> struct MaxTimes {
-    static V initialize() { return -std::numeric_limits<V>::infinity(); }
+    static V initialize() { return Lim<V>::lo(); }
     static V combine(V a, V x) { return a * x; }
     static V reduce(V u, V v) { return u < v ? v : u; }
 };
 template <typename V> struct MaxPlus {
-    static V initialize() { return -std::numeric_limits<V>::infinity(); }
+    static V initialize() { return Lim<V>::lo(); }
     static V combine(V a, V x) { return a + x; }
     static V reduce(V u, V v) { return u < v ? v : u; }
 };
@@ -110,6 +119,25 @@ extern "C" {
     }
 REF_MIXED(i32, int)
 REF_MIXED(i64, long long)
+
+// the reference's generalized serial check on INTEGER values (its template takes any arithmetic type): pins the
+// oracle's integer restatement (values kept small by the callers: signed overflow is undefined in the reference's code)
+#define REF_GENL_INT(SUF, OFF)                                                                 \
+    void ref_spmv_genl_cpu_##SUF(int semiring, int n_rows, int n_cols, OFF nnz, const OFF* Ap, \
+                                 const int* Aj, const int* Ax, const int* x, int* y) {         \
+        if (semiring == 0)                                                                     \
+            SpMV_genl_cpu_navie<PlusTimes<int>, int, OFF, int, int, int>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y); \
+        else if (semiring == 1)                                                                \
+            SpMV_genl_cpu_navie<MinPlus<int>, int, OFF, int, int, int>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);   \
+        else if (semiring == 2)                                                                \
+            SpMV_genl_cpu_navie<MaxTimes<int>, int, OFF, int, int, int>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);  \
+        else if (semiring == 3)                                                                \
+            SpMV_genl_cpu_navie<MaxPlus<int>, int, OFF, int, int, int>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);   \
+        else                                                                                   \
+            SpMV_genl_cpu_navie<OrAnd<int>, int, OFF, int, int, int>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);     \
+    }
+REF_GENL_INT(i32_i32, int)
+REF_GENL_INT(i64_i32, long long)
 
 REF_TYPED(i32_f32, int, float)
 REF_TYPED(i32_f64, int, double)

@@ -75,6 +75,29 @@ void spmv_genl_serial(int semiring, int32_t n_rows, const off_t* Ap, const int32
     }
 }
 
+// The same walk on 32-bit INTEGER values (include/mi355_spmv.h MI355_VAL_I32; the reference's generalized kind is a
+// template over the value types, merge_genl.cuh:134-150, and its CPU twin cpu_navie.hpp:20-34 runs on integers as
+// it stands — oracle/ref_driver.cpp pins this restatement to it).  Identities 0 / INT32_MAX / INT32_MIN, sums and
+// products wrap around (two's complement: computed in uint32_t, so there is no undefined overflow here).
+template <typename off_t>
+void spmv_genl_serial_i32(int semiring, int32_t n_rows, const off_t* Ap, const int32_t* Aj, const int32_t* Ax,
+                          const int32_t* x, int32_t* y) {
+    auto add = [](int32_t a, int32_t b) { return int32_t(uint32_t(a) + uint32_t(b)); };
+    auto mul = [](int32_t a, int32_t b) { return int32_t(uint32_t(a) * uint32_t(b)); };
+    for (int32_t row = 0; row < n_rows; ++row) {
+        int32_t sum = (semiring == 0 || semiring == 4) ? 0 : (semiring == 1 ? INT32_MAX : INT32_MIN);
+        for (off_t k = Ap[row]; k < Ap[row + 1]; ++k) {
+            const int32_t a = Ax[k], b = x[Aj[k]];
+            if (semiring == 0) sum = add(sum, mul(a, b));
+            else if (semiring == 1) { const int32_t v = add(a, b); sum = v < sum ? v : sum; }
+            else if (semiring == 2) { const int32_t v = mul(a, b); sum = sum < v ? v : sum; }
+            else if (semiring == 3) { const int32_t v = add(a, b); sum = sum < v ? v : sum; }
+            else { const int32_t v = (a != 0 && b != 0) ? 1 : 0; sum = (sum != 0 || v != 0) ? 1 : 0; }
+        }
+        y[row] = sum;
+    }
+}
+
 // fp64 serial sum and sum of magnitudes per row: the two quantities of the
 // parity bound stated in SURVEY.md §8(c):
 //   |y_gpu[r] - y64[r]| <= (len_r + 2) * eps * sum_k |Ax[k] * x[Aj[k]]|
@@ -578,6 +601,14 @@ extern "C" {
 ORACLE_MIXED(i32, int32_t)
 ORACLE_MIXED(i64, int64_t)
 
+void oracle_spmv_genl_serial_i32_i32(int semiring, int32_t n_rows, const int32_t* Ap, const int32_t* Aj,
+                                     const int32_t* Ax, const int32_t* x, int32_t* y) {
+    spmv_genl_serial_i32<int32_t>(semiring, n_rows, Ap, Aj, Ax, x, y);
+}
+void oracle_spmv_genl_serial_i64_i32(int semiring, int32_t n_rows, const int64_t* Ap, const int32_t* Aj,
+                                     const int32_t* Ax, const int32_t* x, int32_t* y) {
+    spmv_genl_serial_i32<int64_t>(semiring, n_rows, Ap, Aj, Ax, x, y);
+}
 ORACLE_TYPED(i32_f32, int32_t, float)
 ORACLE_TYPED(i32_f64, int32_t, double)
 ORACLE_TYPED(i64_f32, int64_t, float)

@@ -19,13 +19,13 @@ KINDS = {"vector": 0, "merge": 1, "light": 2}
 # labels the C++ host header registers in SPMV_KINDS (host/spmv.h)
 LABELS = {"hip_vector": "vector", "hip_merge": "merge", "hip_light": "light"}
 OFF_TYPES = {torch.int32: (0, "i32"), torch.int64: (1, "i64")}
-VAL_TYPES = {torch.float32: (0, "f32"), torch.float64: (1, "f64")}
+VAL_TYPES = {torch.float32: (0, "f32"), torch.float64: (1, "f64"), torch.int32: (2, "i32")}   # (int32 values: the merge kind only)
 PLAN_REUSE_STRUCTURE = 1
 SEMIRINGS = {"plus_times": 0, "min_plus": 1, "max_times": 2, "max_plus": 3, "or_and": 4}
 
 EXPORTS = (
     ["mi355_spmv_%s_%s_%s" % (k, o, v) for k in KINDS for o in ("i32", "i64") for v in ("f32", "f64")]
-    + ["mi355_spmv_merge_genl_%s_%s" % (o, v) for o in ("i32", "i64") for v in ("f32", "f64")]
+    + ["mi355_spmv_merge_genl_%s_%s" % (o, v) for o in ("i32", "i64") for v in ("f32", "f64", "i32")]
     + ["mi355_spmv_plan_set_semiring", "mi355_spmv_plan_set_alpha_beta"]
     + ["mi355_spmv_plan_create", "mi355_spmv_plan_execute", "mi355_spmv_plan_destroy",
        "mi355_spmv_plan_get_info", "mi355_spmv_stream_synchronize", "mi355_spmv_plan_merge_coords", "mi355_spmv_version",
@@ -152,6 +152,10 @@ def spmv(kind, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream=None):
     _require_device(Ap, Aj, Ax, x, y)
     if Aj.dtype != torch.int32 or Ax.dtype != x.dtype or Ax.dtype != y.dtype:
         raise TypeError("Aj must be int32 and Ax, x, y one value type")
+    if Ax.dtype == torch.int32:            # integer values exist for the (generalized) merge kind only
+        if LABELS.get(kind, kind) != "merge":
+            raise RuntimeError("mi355_spmv: integer values are not supported by the %s kind (merge only)" % kind)
+        return spmv_genl("plus_times", n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream)
     o = OFF_TYPES[Ap.dtype][1]
     v = VAL_TYPES[Ax.dtype][1]
     fn = getattr(lib(), "mi355_spmv_%s_%s_%s" % (kind, o, v))

@@ -202,7 +202,11 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
     *out = nullptr;
     if (kind < 0 || kind >= MI355_KIND_COUNT) { set_error("plan_create: unknown kind %d", kind); return MI355_SPMV_EINVAL; }
     if (off_type != MI355_OFF_I32 && off_type != MI355_OFF_I64) { set_error("plan_create: unknown offset type %d", off_type); return MI355_SPMV_EINVAL; }
-    if (val_type != MI355_VAL_F32 && val_type != MI355_VAL_F64) { set_error("plan_create: unknown value type %d", val_type); return MI355_SPMV_EINVAL; }
+    if (val_type != MI355_VAL_F32 && val_type != MI355_VAL_F64 && val_type != MI355_VAL_I32) { set_error("plan_create: unknown value type %d", val_type); return MI355_SPMV_EINVAL; }
+    if (val_type == MI355_VAL_I32 && kind != MI355_KIND_MERGE) {
+        set_error("plan_create: integer values are a feature of the generalized merge kind (as the functor is in the reference)");
+        return MI355_SPMV_ENOTSUP;
+    }
     if (n_rows < 0 || n_cols < 0 || nnz < 0) { set_error("plan_create: negative size"); return MI355_SPMV_EINVAL; }
     // the kernels step 16-byte groups past a row's end before masking: 32-bit index arithmetic needs headroom
     if (off_type == MI355_OFF_I32 && nnz > INT32_MAX - 4096) { set_error("plan_create: nnz does not fit 32-bit offsets with headroom (use 64-bit offsets)"); return MI355_SPMV_EINVAL; }
@@ -321,7 +325,7 @@ int mi355_spmv_plan_create_typed(mi355_spmv_plan** out, int kind, int off_type, 
                                  int32_t n_rows, int32_t n_cols, int64_t nnz, const void* Ap, const int32_t* Aj, int flags) {
     g_err[0] = 0;
     if (out) *out = nullptr;
-    const auto known = [](int t) { return t == MI355_VAL_F32 || t == MI355_VAL_F64; };
+    const auto known = [](int t) { return t == MI355_VAL_F32 || t == MI355_VAL_F64 || t == MI355_VAL_I32; };
     if (!known(mat_type) || !known(x_type) || !known(y_type)) { set_error("plan_create_typed: unknown value type"); return MI355_SPMV_EINVAL; }
     if (x_type != y_type) { set_error("plan_create_typed: x and y of different types are not built"); return MI355_SPMV_ENOTSUP; }
     if (mat_type == x_type) return plan_create_impl(out, kind, off_type, x_type, n_rows, n_cols, nnz, Ap, Aj, flags, nullptr);
@@ -383,6 +387,14 @@ int mi355_spmv_plan_execute(mi355_spmv_plan* h, const void* Ax, const void* x, v
     if (p.nnz > 0 && (!Ax || !x)) { set_error("plan_execute: null Ax or x"); return MI355_SPMV_EINVAL; }
     if (p.n_rows > 0 && !y) { set_error("plan_execute: null y"); return MI355_SPMV_EINVAL; }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (p.val_type == MI355_VAL_I32) {      // (MERGE only: plan_create refuses the other kinds)
+        const int32_t* ax = static_cast<const int32_t*>(Ax);
+        const int32_t* xx = static_cast<const int32_t*>(x);
+        int32_t* yy = static_cast<int32_t*>(y);
+        return p.off_type == MI355_OFF_I32
+                   ? launch_merge<int32_t, int32_t, int32_t>(p, static_cast<const int32_t*>(p.Ap), ax, xx, yy, s)
+                   : launch_merge<int64_t, int32_t, int32_t>(p, static_cast<const int64_t*>(p.Ap), ax, xx, yy, s);
+    }
     if (p.off_type == MI355_OFF_I32) {
         return p.val_type == MI355_VAL_F32 ? execute_typed<int32_t, float>(p, Ax, x, y, s)
                                            : execute_typed<int32_t, double>(p, Ax, x, y, s);
@@ -423,6 +435,10 @@ int mi355_spmv_plan_set_alpha_beta(mi355_spmv_plan* h, double alpha, double beta
     if (!h) { set_error("plan_set_alpha_beta: null plan"); return MI355_SPMV_EINVAL; }
     if (h->p.semiring != MI355_SEMIRING_PLUS_TIMES && (alpha != 1.0 || beta != 0.0)) {
         set_error("plan_set_alpha_beta: scaling is defined for the (+, *) semiring only");
+        return MI355_SPMV_ENOTSUP;
+    }
+    if (h->p.val_type == MI355_VAL_I32 && (alpha != 1.0 || beta != 0.0)) {
+        set_error("plan_set_alpha_beta: not for integer values");
         return MI355_SPMV_ENOTSUP;
     }
     h->p.alpha = alpha;
@@ -504,6 +520,8 @@ MI355_SPMV_DEFINE_GENL(i32_f32, int32_t, MI355_OFF_I32, float, MI355_VAL_F32)
 MI355_SPMV_DEFINE_GENL(i32_f64, int32_t, MI355_OFF_I32, double, MI355_VAL_F64)
 MI355_SPMV_DEFINE_GENL(i64_f32, int64_t, MI355_OFF_I64, float, MI355_VAL_F32)
 MI355_SPMV_DEFINE_GENL(i64_f64, int64_t, MI355_OFF_I64, double, MI355_VAL_F64)
+MI355_SPMV_DEFINE_GENL(i32_i32, int32_t, MI355_OFF_I32, int32_t, MI355_VAL_I32)
+MI355_SPMV_DEFINE_GENL(i64_i32, int64_t, MI355_OFF_I64, int32_t, MI355_VAL_I32)
 
 #define MI355_SPMV_DEFINE_MIXED(SUF, OFF, OFFENUM)                                                            \
     int mi355_spmv_merge_f32mat_f64vec_##SUF(int32_t n_rows, int32_t n_cols, OFF nnz, const OFF* Ap,             \

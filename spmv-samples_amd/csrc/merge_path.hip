@@ -64,6 +64,16 @@ constexpr int kMergeSuperItems = 32768;                   // items one workgroup
 // include/spmv/cpu_navie.hpp:20-34) and ships one instance, (+, *).  A C ABI cannot take a C++
 // functor, so the semirings are enumerated (include/mi355_spmv.h).  min/max never round, so
 // MIN_PLUS and MAX_TIMES results are bit-exact whatever the reduction order.
+// "infinities" of a value type: +-inf for floating point, the extreme integers for int32 (min-plus / max-plus on
+// integer weights: an identity only ever meets reduce(), never combine(), so it cannot overflow)
+template <typename val_t> struct Extreme {
+    __device__ static __forceinline__ val_t hi() { return val_t(INFINITY); }
+    __device__ static __forceinline__ val_t lo() { return val_t(-INFINITY); }
+};
+template <> struct Extreme<int32_t> {
+    __device__ static __forceinline__ int32_t hi() { return INT32_MAX; }
+    __device__ static __forceinline__ int32_t lo() { return INT32_MIN; }
+};
 template <int S, typename val_t> struct Semiring;
 template <typename val_t> struct Semiring<MI355_SEMIRING_PLUS_TIMES, val_t> {
     __device__ static __forceinline__ val_t identity() { return val_t(0); }
@@ -71,18 +81,18 @@ template <typename val_t> struct Semiring<MI355_SEMIRING_PLUS_TIMES, val_t> {
     __device__ static __forceinline__ val_t reduce(val_t u, val_t v) { return u + v; }
 };
 template <typename val_t> struct Semiring<MI355_SEMIRING_MIN_PLUS, val_t> {
-    __device__ static __forceinline__ val_t identity() { return val_t(INFINITY); }
+    __device__ static __forceinline__ val_t identity() { return Extreme<val_t>::hi(); }
     __device__ static __forceinline__ val_t combine(val_t a, val_t x) { return a + x; }
     __device__ static __forceinline__ val_t reduce(val_t u, val_t v) { return v < u ? v : u; }
 };
 template <typename val_t> struct Semiring<MI355_SEMIRING_MAX_TIMES, val_t> {
-    __device__ static __forceinline__ val_t identity() { return val_t(-INFINITY); }
+    __device__ static __forceinline__ val_t identity() { return Extreme<val_t>::lo(); }
     __device__ static __forceinline__ val_t combine(val_t a, val_t x) { return a * x; }
     __device__ static __forceinline__ val_t reduce(val_t u, val_t v) { return u < v ? v : u; }
 };
 
 template <typename val_t> struct Semiring<MI355_SEMIRING_MAX_PLUS, val_t> {
-    __device__ static __forceinline__ val_t identity() { return val_t(-INFINITY); }
+    __device__ static __forceinline__ val_t identity() { return Extreme<val_t>::lo(); }
     __device__ static __forceinline__ val_t combine(val_t a, val_t x) { return a + x; }
     __device__ static __forceinline__ val_t reduce(val_t u, val_t v) { return u < v ? v : u; }
 };
@@ -608,7 +618,7 @@ static bool merge_search_in_kernel(const Plan& p) {
 // 5.0-5.4 TB/s is then also ahead of the CSR-vector kind.  MI355_MERGE_ROWS = 0 | 1 overrides.
 static bool merge_rows_wanted(const Plan& p) {
     if (p.knob.merge_rows >= 0) return p.knob.merge_rows != 0;
-    if (!p.probe_ok || p.n_rows <= 0) return false;
+    if (!p.probe_ok || p.n_rows <= 0 || p.val_type == MI355_VAL_I32) return false;
     if (p.tiles_per_super * p.tile_items < 16384) return false;
     for (const int64_t step : {8, 32, 128})
         if (p.probe_len_max <= step && p.probe_len_min * 4 >= step * 3) return true;
@@ -684,7 +694,7 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
     const bool wide = p.block_threads == kWideBlock && p.semiring == MI355_SEMIRING_PLUS_TIMES;
     // the tile kernel finds its run's coordinates itself (no search kernel in front) on the 16-byte path with 256 threads
     // regular matrix: row-parallel runs (plus-times, one value type, 16-byte path); the kernel searches its own diagonals
-    if constexpr (std::is_same<val_t, mat_t>::value) {
+    if constexpr (std::is_same<val_t, mat_t>::value && std::is_floating_point<val_t>::value) {
         if (p.merge_rows && vec && p.semiring == MI355_SEMIRING_PLUS_TIMES) {
             constexpr int RR = sizeof(val_t) == 4 ? 4 : 2;
             const int32_t capw = (int32_t)p.window_elems;
@@ -800,5 +810,8 @@ template int launch_merge<int64_t, double, double>(Plan&, const int64_t*, const 
 // fp32 matrix under fp64 vectors (mi355_spmv_plan_create_typed)
 template int launch_merge<int32_t, double, float>(Plan&, const int32_t*, const float*, const double*, double*, hipStream_t);
 template int launch_merge<int64_t, double, float>(Plan&, const int64_t*, const float*, const double*, double*, hipStream_t);
+// 32-bit integer values (MI355_VAL_I32: every semiring, exact)
+template int launch_merge<int32_t, int32_t, int32_t>(Plan&, const int32_t*, const int32_t*, const int32_t*, int32_t*, hipStream_t);
+template int launch_merge<int64_t, int32_t, int32_t>(Plan&, const int64_t*, const int32_t*, const int32_t*, int32_t*, hipStream_t);
 
 }  // namespace mi355

@@ -25,6 +25,7 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 template <typename val_t> struct Vec4;
 template <> struct Vec4<float> { using type = float4v; };
 template <> struct Vec4<double> { using type = double4v; };
+template <> struct Vec4<int32_t> { using type = int4v; };   // (integer values: the generalized merge kind)
 
 // Aj / Ax are read exactly once per SpMV: stream them past the caches (nontemporal) so
 // that the lines of x, which ARE re-used, stay resident.  Measured on the two-stream

@@ -270,6 +270,7 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 
 // ... and a float / double that is the same in every lane (an LDS word every thread reads).
 __device__ __forceinline__ float uniform_val(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ int32_t uniform_val(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ double uniform_val(double v) { return __longlong_as_double(uniform_i64(__double_as_longlong(v))); }
 
 // Row offsets of either width behind one kernel signature (a uniform branch per load, in prologues only).

@@ -45,7 +45,7 @@ struct PlusTimes { static constexpr int id = MI355_SEMIRING_PLUS_TIMES; };   // 
 struct MinPlus   { static constexpr int id = MI355_SEMIRING_MIN_PLUS; };
 struct MaxTimes  { static constexpr int id = MI355_SEMIRING_MAX_TIMES; };
 struct MaxPlus   { static constexpr int id = MI355_SEMIRING_MAX_PLUS; };
-struct OrAnd     { static constexpr int id = MI355_SEMIRING_OR_AND; };     // booleans as 0.0 / 1.0
+struct OrAnd     { static constexpr int id = MI355_SEMIRING_OR_AND; };     // booleans as 0.0 / 1.0 (or 0 / 1 on int values)
 
 template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,
           typename vec_y_value_t>
@@ -61,15 +61,17 @@ void run_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const offs
     // fp64 vectors (the reference's template keeps the three apart, spmv.h:29-34; merge_genl.cuh:29-31 computes in
     // the y type).  Anything else is not built: mi355_spmv_plan_create_typed returns ENOTSUP and the check aborts.
     static_assert(std::is_same<vec_x_value_t, vec_y_value_t>::value, "mi355 kinds: x and y share one value type");
-    static_assert((std::is_same<mat_value_t, float>::value || std::is_same<mat_value_t, double>::value) &&
-                      (std::is_same<vec_x_value_t, float>::value || std::is_same<vec_x_value_t, double>::value),
-                  "mi355 kinds: value types are float or double");
+    // ... or 32-bit integers throughout (the merge kinds: every semiring of the generalized kind, exact)
+    constexpr bool all_int = std::is_same<mat_value_t, int>::value && std::is_same<vec_x_value_t, int>::value;
+    static_assert(all_int || ((std::is_same<mat_value_t, float>::value || std::is_same<mat_value_t, double>::value) &&
+                              (std::is_same<vec_x_value_t, float>::value || std::is_same<vec_x_value_t, double>::value)),
+                  "mi355 kinds: value types are float or double (or int throughout, merge kinds)");
     static_assert(std::is_same<mat_value_t, vec_x_value_t>::value ||
                       (std::is_same<mat_value_t, float>::value && std::is_same<vec_x_value_t, double>::value),
                   "mi355 kinds: the only mixed combination is an fp32 matrix under fp64 vectors");
     const int off_type = sizeof(offset_t) == 8 ? MI355_OFF_I64 : MI355_OFF_I32;
-    const int mat_type = std::is_same<mat_value_t, double>::value ? MI355_VAL_F64 : MI355_VAL_F32;
-    const int vec_type = std::is_same<vec_x_value_t, double>::value ? MI355_VAL_F64 : MI355_VAL_F32;
+    const int mat_type = all_int ? MI355_VAL_I32 : std::is_same<mat_value_t, double>::value ? MI355_VAL_F64 : MI355_VAL_F32;
+    const int vec_type = all_int ? MI355_VAL_I32 : std::is_same<vec_x_value_t, double>::value ? MI355_VAL_F64 : MI355_VAL_F32;
 
     mi355_spmv_plan* plan = nullptr;
     MI355_CHECK(mi355_spmv_plan_create_typed(&plan, kind, off_type, mat_type, vec_type, vec_type, (int32_t)n_rows,

@@ -9,6 +9,7 @@
 //                                 reference's message and exit(EXIT_FAILURE) (spmv.h:46-47)
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -157,6 +158,57 @@ static int run_mixed() {
     return failures;
 }
 
+// integer values through the template boundary: SpMV_hip_merge_generalized<MinPlus, int, long long, int, int, int>
+// (the reference's generalized kind is a template over the value types and the functor) — exact against a serial loop
+static int run_integer() {
+    const int n_rows = 5003, n_cols = 800;
+    unsigned long long seed = 4242;
+    std::vector<long long> Ap(n_rows + 1, 0);
+    std::vector<int> Aj, Ax;
+    for (int r = 0; r < n_rows; ++r) {
+        const int len = (r == 77) ? 7000 : int(lcg(seed) % 15u);
+        for (int k = 0; k < len; ++k) {
+            Aj.push_back(int(lcg(seed) % (unsigned)n_cols));
+            Ax.push_back(int(lcg(seed) % 41u) - 20);
+        }
+        Ap[r + 1] = (long long)Aj.size();
+    }
+    const long long nnz = (long long)Aj.size();
+    std::vector<int> x(n_cols), y(n_rows);
+    for (int c = 0; c < n_cols; ++c) x[c] = int(lcg(seed) % 61u) - 30;
+    long long* dAp; int *dAj, *dAx, *dX, *dY;
+    HIP_OK(hipMalloc((void**)&dAp, (n_rows + 1) * sizeof(long long)));
+    HIP_OK(hipMalloc((void**)&dAj, (size_t(nnz) + 4) * sizeof(int)));
+    HIP_OK(hipMalloc((void**)&dAx, (size_t(nnz) + 4) * sizeof(int)));
+    HIP_OK(hipMalloc((void**)&dX, n_cols * sizeof(int)));
+    HIP_OK(hipMalloc((void**)&dY, n_rows * sizeof(int)));
+    HIP_OK(hipMemcpy(dAp, Ap.data(), (n_rows + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dAj, Aj.data(), size_t(nnz) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dAx, Ax.data(), size_t(nnz) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dX, x.data(), n_cols * sizeof(int), hipMemcpyHostToDevice));
+    int failures = 0;
+    for (int which = 0; which < 2; ++which) {          // 0: (+, *), 1: (min, +)
+        std::vector<int> poison(n_rows, 123456789);
+        HIP_OK(hipMemcpy(dY, poison.data(), n_rows * sizeof(int), hipMemcpyHostToDevice));
+        if (which == 0) SpMV_hip_merge_generalized<mi355_host::PlusTimes, int, long long, int, int, int>(n_rows, n_cols, nnz, dAp, dAj, dAx, dX, dY);
+        else SpMV_hip_merge_generalized<mi355_host::MinPlus, int, long long, int, int, int>(n_rows, n_cols, nnz, dAp, dAj, dAx, dX, dY);
+        HIP_OK(hipMemcpy(y.data(), dY, n_rows * sizeof(int), hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int r = 0; r < n_rows; ++r) {
+            long long s = which == 0 ? 0 : std::numeric_limits<int>::max();
+            for (long long k = Ap[r]; k < Ap[r + 1]; ++k) {
+                if (which == 0) s += (long long)Ax[k] * x[Aj[k]];
+                else s = std::min<long long>(s, (long long)Ax[k] + x[Aj[k]]);
+            }
+            if (y[r] != int(s)) ++bad;
+        }
+        std::printf("[genl on int    ] %s rows=%d nnz=%lld bad_rows=%d\n", which == 0 ? "(+,*)" : "(min,+)", n_rows, nnz, bad);
+        failures += bad ? 1 : 0;
+    }
+    HIP_OK(hipFree(dAp)); HIP_OK(hipFree(dAj)); HIP_OK(hipFree(dAx)); HIP_OK(hipFree(dX)); HIP_OK(hipFree(dY));
+    return failures;
+}
+
 int main(int argc, char** argv) {
     HIP_OK(hipSetDevice(0));  // USED_DEVICE 0 (common.cuh:8)
     if (argc > 1 && std::strcmp(argv[1], "--bad-label") == 0) {
@@ -172,6 +224,7 @@ int main(int argc, char** argv) {
     failures += run_combo<long long, float>("i64_f32", 3001, 2500, 24);
     failures += run_combo<long long, double>("i64_f64", 777, 1, 3);  // n_cols == 1
     failures += run_mixed();
+    failures += run_integer();
     std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
     return failures ? 1 : 0;
 }

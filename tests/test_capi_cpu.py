@@ -21,9 +21,8 @@ def declared_symbols():
             continue
         for suf in ("i32_f32", "i32_f64", "i64_f32", "i64_f64"):
             names.add("mi355_spmv_%s_%s" % (kind, suf))
-    if "MI355_SPMV_DECLARE_GENL(" in text:
-        for suf in ("i32_f32", "i32_f64", "i64_f32", "i64_f64"):
-            names.add("mi355_spmv_merge_genl_%s" % suf)
+    for suf in re.findall(r"^MI355_SPMV_DECLARE_GENL\((\w+),", text, flags=re.M):
+        names.add("mi355_spmv_merge_genl_%s" % suf)
     return {n for n in names if "##" not in n}
 
 

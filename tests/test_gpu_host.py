@@ -33,6 +33,7 @@ def test_cpp_boundary_all_labels_and_types():
                   "hip_dist_light"):
         assert r.stdout.count("[%-14s]" % label) == (5 if label in ("hip_merge", "hip_merge_genl") else 4)
     assert r.stdout.count("f32mat_f64vec") == 2
+    assert r.stdout.count("[genl on int    ]") == 2          # (+,*) and (min,+) on 32-bit integer values, 64-bit offsets
 
 
 def test_cpp_boundary_unknown_label_exits_like_the_reference():

@@ -647,6 +647,54 @@ def test_generalized_merge_semirings(sp, oracle, semiring, off, val):
         assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("semiring", ["plus_times", "min_plus", "max_times", "max_plus", "or_and"])
+@pytest.mark.parametrize("off", ["i32", "i64"])
+def test_generalized_merge_on_integer_values(sp, oracle, semiring, off):
+    """32-bit integer values (MI355_VAL_I32; the reference's generalized kind is a template over the value types):
+    every semiring bit-exact against the oracle — ragged rows, empty rows (identity 0 / INT32_MAX / INT32_MIN), a
+    long row across many tiles, a matrix big enough for several runs; one-shot symbol and a kept plan."""
+    rng = np.random.RandomState(90 + len(semiring))
+    Ap, Aj, _ = random_csr(rng, 60011, 3000, 40, NP[off], np.float32, long_row=70000)
+    nnz = int(Ap[-1])
+    Ax = rng.randint(-9, 10, size=nnz).astype(np.int32)
+    x = rng.randint(-7, 8, size=3000).astype(np.int32)
+    if semiring == "or_and":
+        Ax = (rng.rand(nnz) < 0.5).astype(np.int32)
+        x = (rng.rand(3000) < 0.1).astype(np.int32)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    dAp, dAj, dAx, dx = d(Ap), d(Aj), d(Ax), d(x)
+    y = torch.full((60011,), 12345, dtype=torch.int32, device=DEV)
+    sp.spmv_genl(semiring, 60011, 3000, nnz, dAp, dAj, dAx, dx, y)
+    want = oracle.spmv_genl_serial(sp.capi.SEMIRINGS[semiring], Ap, Aj, Ax, x)
+    assert np.array_equal(y.cpu().numpy(), want)
+    assert (np.diff(Ap.astype(np.int64)) == 0).any()
+    p = sp.Plan("merge", 60011, 3000, nnz, dAp, dAj, torch.int32)
+    p.set_semiring(semiring)
+    y2 = torch.full((60011,), -777, dtype=torch.int32, device=DEV)
+    p.execute(dAx, dx, y2)
+    p.execute(dAx, dx, y2)
+    torch.cuda.synchronize()
+    assert np.array_equal(y2.cpu().numpy(), want)
+    with pytest.raises(RuntimeError, match="not supported"):
+        p.set_alpha_beta(2.0, 0.0)
+    p.destroy()
+
+
+def test_integer_values_are_a_merge_feature_and_wrap_around(sp, oracle):
+    rng = np.random.RandomState(7)
+    Ap, Aj, _ = random_csr(rng, 3000, 500, 20, np.int32, np.float32)
+    nnz = int(Ap[-1])
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    for kind in ("vector", "light"):
+        with pytest.raises(RuntimeError, match="not supported"):
+            sp.Plan(kind, 3000, 500, nnz, d(Ap), d(Aj), torch.int32)
+    Ax = np.full(nnz, 2 ** 30, dtype=np.int32)                 # sums far beyond 2^31: two's-complement wrap-around
+    x = np.full(500, 3, dtype=np.int32)
+    y = torch.zeros(3000, dtype=torch.int32, device=DEV)
+    sp.spmv("merge", 3000, 500, nnz, d(Ap), d(Aj), d(Ax), d(x), y)
+    assert np.array_equal(y.cpu().numpy(), oracle.spmv_genl_serial(0, Ap, Aj, Ax, x))
+
+
 def test_semiring_is_a_merge_feature_and_plans_keep_it(sp, oracle):
     rng = np.random.RandomState(78)
     Ap, Aj, Ax = random_csr(rng, 5000, 300, 12)

@@ -200,6 +200,39 @@ def test_generalized_serial_matches_reference_build(oracle, ref, semiring, off, 
         assert np.array_equal(got, oracle.spmv_serial(Ap, Aj, Ax, x))
 
 
+@pytest.mark.parametrize("semiring", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("off", ["i32", "i64"])
+def test_generalized_serial_on_integer_values(oracle, ref, semiring, off):
+    """32-bit integer values (MI355_VAL_I32): the restatement against the reference's own SpMV_genl_cpu_navie
+    instantiated on int (oracle/ref_driver.cpp) and against a plain numpy loop — exact; empty rows yield the identity
+    (0 / INT32_MAX / INT32_MIN); the (+,*) sum wraps around like the GPU's (checked against numpy's modular int32)."""
+    rng = np.random.RandomState(60 + semiring)
+    Ap, Aj, _ = random_csr(rng, 400, 150, 25, NP[off], np.float32, long_row=700)
+    nnz = int(Ap[-1])
+    Ax = rng.randint(-9, 10, size=nnz).astype(np.int32)
+    x = rng.randint(-7, 8, size=150).astype(np.int32)
+    if semiring == 4:
+        Ax = (rng.rand(nnz) < 0.5).astype(np.int32)
+        x = (rng.rand(150) < 0.3).astype(np.int32)
+    got = oracle.spmv_genl_serial(semiring, Ap, Aj, Ax, x)
+    assert got.dtype == np.int32
+    assert np.array_equal(got, ref.spmv_genl_cpu(semiring, 150, Ap, Aj, Ax, x))
+    ident = {0: 0, 1: 2 ** 31 - 1, 2: -2 ** 31, 3: -2 ** 31, 4: 0}[semiring]
+    for r in range(400):
+        a, b = Ax[Ap[r]:Ap[r + 1]].astype(np.int64), x[Aj[Ap[r]:Ap[r + 1]]].astype(np.int64)
+        if a.size == 0:
+            assert got[r] == ident
+            continue
+        want = {0: (a * b).sum(), 1: (a + b).min(), 2: (a * b).max(), 3: (a + b).max(), 4: int(((a != 0) & (b != 0)).any())}[semiring]
+        assert got[r] == want
+    if semiring == 0:                                   # wrap-around: defined here (uint32 arithmetic), as on the GPU
+        big = np.full(nnz, 2 ** 30, dtype=np.int32)
+        xs = np.full(150, 3, dtype=np.int32)
+        wrapped = oracle.spmv_genl_serial(0, Ap, Aj, big, xs)
+        lens = np.diff(Ap.astype(np.int64))
+        assert np.array_equal(wrapped, ((lens * (3 * 2 ** 30) + 2 ** 31) % 2 ** 32 - 2 ** 31).astype(np.int32))
+
+
 def test_ref64_threads_do_not_change_values(oracle):
     """The threaded pass used by the BASELINE-sized GPU tests splits ROWS only."""
     rng = np.random.RandomState(5)
