@@ -367,6 +367,10 @@ static bool light_dequeue_once(const Plan& p, int64_t n_chunks, int64_t resident
 void shape_light(Plan& p) {
     p.lanes_per_row = pick_lanes_per_row(p.nnz - p.nnz_begin, p.n_rows, p.elems_per_lane);
     const int R = p.val_type == MI355_VAL_F64 ? light_rows_in_flight<double>() : light_rows_in_flight<float>();
+    {                                                          // tuning knob (as the CSR-vector kind)
+        const int t = p.knob.lanes;
+        if (t == 2 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64) p.lanes_per_row = t;
+    }
     const int div = p.knob.light_chunk_div;
     // chunks: the static kind's size (halving them cost 6 % on the S32-band target: the
     // window of x is staged per chunk), never below one pass of the workgroup
