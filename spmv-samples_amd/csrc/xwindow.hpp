@@ -781,7 +781,6 @@ __device__ __forceinline__ void chunk_rows_sweep(int64_t chunk_begin, int64_t ch
     int4v c[R];
     v4 a[R];
     val_t sum[R];
-    unsigned valid = 0;                                      // bit r * 4 + e: element e of slot r belongs to the row
     // (the row bounds are read from LDS again after the sweep instead of being held in registers across it)
     auto bounds = [&](int r, off_t& lo, off_t& hi, off_t& j) {
         const int row = row_of(r);
@@ -801,8 +800,7 @@ __device__ __forceinline__ void chunk_rows_sweep(int64_t chunk_begin, int64_t ch
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const bool mine = j + e >= lo && j + e < top;
-            if (mine) valid |= 1u << (r * 4 + e);
-            c[r][e] = mine ? c[r][e] : INT32_MAX;            // (a column no window holds: the sweep needs no second test)
+            c[r][e] = mine ? c[r][e] : INT32_MAX;            // (no column: a slot that is not the row's, here and below)
         }
         sum[r] = val_t(0);
     }
@@ -867,7 +865,7 @@ __device__ __forceinline__ void chunk_rows_sweep(int64_t chunk_begin, int64_t ch
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (((valid >> (r * 4 + e)) & 1u) && (c[r][e] < c_lo || c[r][e] > c_hi)) { out |= 1u << (r * 4 + e); any = true; }
+                if (c[r][e] != INT32_MAX && (c[r][e] < c_lo || c[r][e] > c_hi)) { out |= 1u << (r * 4 + e); any = true; }
         if (any) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
