@@ -11,7 +11,7 @@ sp = g.load_package()
 dev = torch.device("cuda:0")
 tag = os.path.basename(os.path.dirname(os.environ.get("MI355_SPMV_LIB", "/lib/x")))
 def timeit(p, m, x, y, n=40):
-    for _ in range(5): p.execute(m.Ax, x, y)
+    for _ in range(40): p.execute(m.Ax, x, y)   # (a big matrix runs its first ~35 executes 10-15 % slower)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()

@@ -9,7 +9,7 @@ import __graft_entry__ as g
 sp = g.load_package()
 dev = torch.device("cuda:0")
 def timeit(p, m, x, y, n=20):
-    for _ in range(3): p.execute(m.Ax, x, y)
+    for _ in range(40): p.execute(m.Ax, x, y)   # (a big matrix runs its first ~35 executes 10-15 % slower)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()

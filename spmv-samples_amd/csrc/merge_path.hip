@@ -611,11 +611,11 @@ static bool merge_search_in_kernel(const Plan& p) {
 // (the widths the run body picks from: 8, 32, 128 nonzeros per step) — the probe's 256 sampled rows all hold between
 // three quarters of such a step and the whole of it — and big enough for runs of 16 K+ items (on a small matrix a run
 // is a tile or two: the window and the two diagonals cost more than they are worth — cant stand-in 40.6 us against 19.5
-// with the item walk).  Measured on 2^27 nonzeros (us, runs / item walk; scripts/gpu_r02_merge_regular.py): fixed 8 per
-// row 345 / 404, 27: 243 / 268, 32: 222 / 262, 100: 232 / 240, 128: 201 / 237 — but 12: 491 / 354, 16: 363 / 300,
-// 40: 411 / 258, 64: 282 / 251 (half the lanes idle, or a second dependent step), and rows of VARYING length lose
-// at every mean (24 +- 6: 397 / 326, 64 +- 16: 514 / 403, 128 +- 32: 489 / 380): those keep the item walk, which at
-// 5.0-5.4 TB/s is then also ahead of the CSR-vector kind.  MI355_MERGE_ROWS = 0 | 1 overrides.
+// with the item walk).  Measured on 2^27 nonzeros (us, runs / item walk; scripts/gpu_r02_merge_regular.py,
+// profiles/r02_row_length_scan.txt): fixed 8 per row 341 / 408, 27: 245 / 269, 32: 206 / 252, 100: 229 / 241, 128: 193 / 237
+// — but 12: 494 / 356, 16: 371 / 312, 40: 402 / 250, 64: 273 / 242 (half the lanes idle, or a second dependent step),
+// and rows of VARYING length lose at every mean (24 +- 6: 415 / 341, 64 +- 16: 479 / 381, 128 +- 32: 502 / 380): those
+// keep the item walk, at 4.8-5.5 TB/s.  MI355_MERGE_ROWS = 0 | 1 overrides.
 static bool merge_rows_wanted(const Plan& p) {
     if (p.knob.merge_rows >= 0) return p.knob.merge_rows != 0;
     if (!p.probe_ok || p.n_rows <= 0 || p.val_type == MI355_VAL_I32) return false;
