@@ -607,20 +607,20 @@ static bool merge_search_in_kernel(const Plan& p) {
     return p.n_super <= int64_t(kCus) * 8;
 }
 
-// Row-parallel runs (merge_rows_kernel) for a matrix whose rows all but fill ONE step of a vector of 2, 8 or 32 lanes
-// (the widths the run body picks from: 8, 32, 128 nonzeros per step) — the probe's 256 sampled rows all hold between
-// three quarters of such a step and the whole of it — and big enough for runs of 16 K+ items (on a small matrix a run
-// is a tile or two: the window and the two diagonals cost more than they are worth — cant stand-in 40.6 us against 19.5
-// with the item walk).  Measured on 2^27 nonzeros (us, runs / item walk; scripts/gpu_r02_merge_regular.py,
-// profiles/r02_row_length_scan.txt): fixed 8 per row 341 / 408, 27: 245 / 269, 32: 206 / 252, 100: 229 / 241, 128: 193 / 237
-// — but 12: 494 / 356, 16: 371 / 312, 40: 402 / 250, 64: 273 / 242 (half the lanes idle, or a second dependent step),
-// and rows of VARYING length lose at every mean (24 +- 6: 415 / 341, 64 +- 16: 479 / 381, 128 +- 32: 502 / 380): those
-// keep the item walk, at 4.8-5.5 TB/s.  MI355_MERGE_ROWS = 0 | 1 overrides.
+// Row-parallel runs (merge_rows_kernel) for a matrix whose rows all but fill ONE step of a vector of 2, 4, 8, 16 or 32
+// lanes (the widths the run body picks from: 8, 16, 32, 64, 128 nonzeros per step) — the probe's 256 sampled rows all
+// hold between three quarters of such a step and the whole of it — and big enough for runs of 16 K+ items (on a small
+// matrix a run is a tile or two: the window and the two diagonals cost more than they are worth — cant stand-in 40.6 us
+// against 19.5 with the item walk).  Measured on 2^27 nonzeros (us, runs / item walk; scripts/gpu_r02_merge_regular.py,
+// profiles/r02_row_length_scan.txt): fixed 8 per row 347 / 410, 16: 285 / 315, 27: 251 / 275, 32: 218 / 257, 48: 239 / 256,
+// 64: 205 / 245, 100: 229 / 242, 128: 195 / 237 — but 40: 262 / 256 (a step of 64 is 62 % full), and rows of VARYING length
+// lose at every mean (24 +- 6: 415 / 341, 64 +- 16: 479 / 381, 128 +- 32: 502 / 380): those keep the item walk, at
+// 4.8-5.5 TB/s.  MI355_MERGE_ROWS = 0 | 1 overrides.
 static bool merge_rows_wanted(const Plan& p) {
     if (p.knob.merge_rows >= 0) return p.knob.merge_rows != 0;
     if (!p.probe_ok || p.n_rows <= 0 || p.val_type == MI355_VAL_I32) return false;
     if (p.tiles_per_super * p.tile_items < 16384) return false;
-    for (const int64_t step : {8, 32, 128})
+    for (const int64_t step : {8, 16, 32, 64, 128})
         if (p.probe_len_max <= step && p.probe_len_min * 4 >= step * 3) return true;
     return false;
 }

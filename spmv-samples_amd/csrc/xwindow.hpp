@@ -717,8 +717,8 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
 // 2 000 near-empty rows and chunks of 100 rows x 120 nonzeros; one width for all of them leaves the second
 // kind walking 16 dependent steps per row.  Three widths (2, 8, 32 lanes: rows of <= 8, 32, 128 nonzeros in
 // one step) from the chunk's own mean row length, read from the bounds already in LDS.
-// REGULAR (the merge kind's row-parallel runs: rows alike): the width that takes a mean row in ONE step (8 / 32 / 128
-// nonzeros) — a second, dependent step per row costs such a matrix more than idle lanes do (rows of 64 +- 16 with 8
+// REGULAR (the merge kind's row-parallel runs: rows alike): the width that takes a mean row in ONE step (8 / 16 / 32 /
+// 64 / 128 nonzeros) — a second, dependent step per row costs such a matrix more than idle lanes do (rows of 64 +- 16 with 8
 // lanes: three steps, 740 us; with 32 lanes: see merge_path.hip).
 template <int BLOCK, int T, int R, bool WINDOW, bool ADAPT, typename val_t, typename StageFn, bool REGULAR = false>
 __device__ __forceinline__ void chunk_rows_any(int64_t chunk_begin, int64_t chunk_end, int32_t nnz,
@@ -731,8 +731,16 @@ __device__ __forceinline__ void chunk_rows_any(int64_t chunk_begin, int64_t chun
     } else {
         const int rows = int(chunk_end - chunk_begin);
         const int32_t mean = (scr.s_b[rows] - scr.s_b[0]) / int32_t(rows > 0 ? rows : 1);   // uniform over the workgroup
-        if (mean <= (REGULAR ? 8 : 16)) chunk_rows<BLOCK, 2, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
-        else if (mean <= (REGULAR ? 32 : 64)) chunk_rows<BLOCK, 8, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
+        if constexpr (REGULAR) {       // five widths: one step of 8 / 16 / 32 / 64 / 128 nonzeros
+            if (mean <= 8) chunk_rows<BLOCK, 2, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
+            else if (mean <= 16) chunk_rows<BLOCK, 4, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
+            else if (mean <= 32) chunk_rows<BLOCK, 8, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
+            else if (mean <= 64) chunk_rows<BLOCK, 16, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
+            else chunk_rows<BLOCK, 32, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
+            return;
+        }
+        if (mean <= 16) chunk_rows<BLOCK, 2, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
+        else if (mean <= 64) chunk_rows<BLOCK, 8, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
         else chunk_rows<BLOCK, 32, R, WINDOW, val_t>(chunk_begin, chunk_end, nnz, Aj, Ax, x, y, stage, scr);
     }
 }
