@@ -27,6 +27,16 @@ if os.path.exists(CMP) and "--no-rocsparse" not in sys.argv:
         [ctypes.POINTER(ctypes.c_double)] * 2
 
 
+# warm-up and loop lengths by matrix size: ~25 ms of warm-up (an HBM-bound kernel needs ~12 ms from a fresh start to reach its
+# steady time, profiles/r02_warmup_curve.txt; 5 + 30 calls penalised whoever ran first), ~25 ms timed, same for both sides
+def EST_US(m):
+    return max(8.0, m.algorithmic_bytes() / 4.0e6)          # (at ~4 TB/s)
+def WARM(m):
+    return max(40, int(25e3 / EST_US(m)))
+def ITERS(m):
+    return max(30, int(25e3 / EST_US(m)))
+
+
 def rocsparse_direct(m, x, y_ours):
     """{'adaptive': us, 'stream': us, 'analysis_ms': ms, 'rel_maxdiff': d} or None (64-bit offsets)."""
     if cmp_lib is None or m.nnz >= 2 ** 31:
@@ -42,7 +52,7 @@ def rocsparse_direct(m, x, y_ours):
         torch.cuda.synchronize()
         rc = cmp_lib.cmp_rocsparse_csrmv(0 if m.Ax.dtype == torch.float32 else 1, m.n_rows, m.n_cols, m.nnz,
                                          Ap32.data_ptr(), m.Aj.data_ptr(), m.Ax.data_ptr(), x.data_ptr(),
-                                         y.data_ptr(), analyse, 5, 30, ctypes.byref(us), ctypes.byref(ana))
+                                         y.data_ptr(), analyse, WARM(m), ITERS(m), ctypes.byref(us), ctypes.byref(ana))
         assert rc == 0
         torch.cuda.synchronize()
         res[name + "_us"] = us.value
@@ -66,16 +76,16 @@ for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["s32-band", "c
     y2 = torch.empty_like(y)
     for kind in ("vector", "merge", "light"):
         p = sp.Plan(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype)
-        for _ in range(5):
+        for _ in range(WARM(m)):
             p.execute(m.Ax, x, y2)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        for _ in range(30):
+        for _ in range(ITERS(m)):
             p.execute(m.Ax, x, y2)
         b.record()
         torch.cuda.synchronize()
-        res[kind] = a.elapsed_time(b) / 30 * 1e3
+        res[kind] = a.elapsed_time(b) / ITERS(m) * 1e3
         p.destroy()
     direct = rocsparse_direct(m, x, y2)
     t, err = None, None
