@@ -293,6 +293,20 @@ int mi355_spmv_dist_destroy(mi355_spmv_dist* dist);
  * plans keep the values they were created under and report the non-default ones in plan_info.knobs). */
 int mi355_spmv_knobs_reload(void);
 
+/* The one-shot entry points keep their last few plans, found again by the pointers and sizes of Ap / Aj, the types, the
+ * kind and the device (the reference's harness calls a kind 2 000 times in a row on one matrix, main.cu:102-113; plan
+ * creation is a third of such a call on the target).  Safe if the arrays were rewritten in place: a kept plan holds
+ * launch-shape decisions only (plans with giant rows, whose row list is structure, are never kept).
+ * MI355_SPMV_PLAN_CACHE=0 disables it; this call destroys the kept plans and frees their scratch.                  */
+int mi355_spmv_cache_release(void);
+/* The same for a caller that wants its own timer between the steps (the C++ mirror of the reference boundary,
+ * host/spmv/mi355.hpp): acquire = a kept plan for this matrix or a new default plan; release = hand it back after the
+ * stream it ran on has been synchronised (executed_ok = 0 after a failed execute: the plan is destroyed).  A plan whose
+ * semiring was changed is handed back with it (the next acquirer sets its own); alpha / beta other than 1 / 0 are not kept. */
+int mi355_spmv_plan_acquire(mi355_spmv_plan** plan, int kind, int off_type, int val_type, int32_t n_rows,
+                            int32_t n_cols, int64_t nnz, const void* Ap, const int32_t* Aj);
+int mi355_spmv_plan_release(mi355_spmv_plan* plan, int executed_ok);
+
 /* MERGE only, for parity tests: copy the tile start coordinates the search
  * kernel produced by the last execute to HOST arrays of n_tiles+1 entries
  * (synchronises).  Integers: compared bit-exactly with the oracle's restatement

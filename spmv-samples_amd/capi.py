@@ -31,7 +31,8 @@ EXPORTS = (
        "mi355_spmv_plan_get_info", "mi355_spmv_stream_synchronize", "mi355_spmv_plan_merge_coords", "mi355_spmv_version",
        "mi355_spmv_status_string", "mi355_spmv_last_error", "mi355_spmv_device_count"]
     + ["mi355_spmv_plan_get_shape", "mi355_spmv_plan_partition", "mi355_spmv_plan_create_block",
-       "mi355_spmv_knobs_reload", "mi355_spmv_plan_create_typed", "mi355_spmv_merge_f32mat_f64vec_i32",
+       "mi355_spmv_knobs_reload", "mi355_spmv_cache_release", "mi355_spmv_plan_acquire", "mi355_spmv_plan_release",
+       "mi355_spmv_plan_create_typed", "mi355_spmv_merge_f32mat_f64vec_i32",
        "mi355_spmv_merge_f32mat_f64vec_i64"]
     + ["mi355_spmv_dist_" + n for n in ("create_local", "unique_id", "create_rank", "scatter_values", "replicate_x",
                                         "execute", "set_alpha_beta", "parts", "cuts", "part_info", "device_y", "device_x",
@@ -178,6 +179,11 @@ def spmv_mixed(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream=None):
             C.c_void_p(Ax.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), _stream_ptr(stream))
     _check(st, "mi355_spmv_merge_f32mat_f64vec_%s" % o)
     return y
+
+
+def cache_release():
+    """Destroy the plans the one-shot entry points keep between calls (mi355_spmv_cache_release)."""
+    _check(lib().mi355_spmv_cache_release(), "mi355_spmv_cache_release")
 
 
 def spmv_genl(semiring, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream=None):

@@ -10,6 +10,7 @@
 
 struct mi355_spmv_plan {   // the opaque handle of include/mi355_spmv.h
     mi355::Plan p;
+    int acquired_on = -1;  // device of a plan handed out by mi355_spmv_plan_acquire (-1: an ordinary plan)
 };
 
 namespace mi355 {
@@ -121,14 +122,114 @@ static int execute_typed(Plan& p, const void* Ax, const void* x, void* y, hipStr
     return MI355_SPMV_EINVAL;
 }
 
+// The one-shot entry points keep their last few plans (the reference re-creates everything per call, and
+// its harness calls a kind 2 000 times in a row on the same matrix, main.cu:102-113 — plan creation, two small kernels and
+// two host round trips, is ~90 us of a 270 us call on the target and six times the kernel on the cant stand-in).  A plan is
+// found again by the POINTERS and sizes of the structure arrays, the types, the kind and the device.  That is safe when the
+// caller has rewritten Ap / Aj in place or re-used the addresses for another matrix of the same sizes: everything a plan
+// holds about the structure is a launch-shape decision with a fallback in the kernels (columns outside a window are
+// gathered from memory, rows longer than a step finish in the long-row passes, chunk tables are row partitions whatever
+// the rows hold, merge coordinates are recomputed by every execute) — except the list of giant rows, so a plan that has
+// one is never kept.  MI355_SPMV_PLAN_CACHE=0 turns it off; mi355_spmv_cache_release() frees what it holds.
+struct OneShotKey {
+    int device, kind, off_type, val_type;
+    int32_t n_rows, n_cols;
+    int64_t nnz;
+    const void *Ap, *Aj;
+    bool operator==(const OneShotKey& o) const {
+        return device == o.device && kind == o.kind && off_type == o.off_type && val_type == o.val_type && n_rows == o.n_rows &&
+               n_cols == o.n_cols && nnz == o.nnz && Ap == o.Ap && Aj == o.Aj;
+    }
+};
+struct OneShotSlot { OneShotKey key; mi355_spmv_plan* plan = nullptr; };
+constexpr int kOneShotSlots = 6;
+static std::mutex g_oneshot_mutex;
+static OneShotSlot g_oneshot[kOneShotSlots];
+static int g_oneshot_next = 0;
+
+static bool oneshot_cache_enabled() {
+    static const bool on = [] { const char* e = getenv("MI355_SPMV_PLAN_CACHE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+static mi355_spmv_plan* oneshot_take(const OneShotKey& key) {
+    std::lock_guard<std::mutex> lock(g_oneshot_mutex);
+    for (OneShotSlot& s : g_oneshot)
+        if (s.plan && s.key == key) {
+            mi355_spmv_plan* p = s.plan;
+            s.plan = nullptr;          // (taken OUT: a second thread with the same matrix makes its own plan)
+            return p;
+        }
+    return nullptr;
+}
+
+static void oneshot_keep(const OneShotKey& key, mi355_spmv_plan* plan) {
+    mi355_spmv_plan* evicted = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_oneshot_mutex);
+        OneShotSlot* slot = nullptr;
+        for (OneShotSlot& s : g_oneshot)
+            if (!s.plan) { slot = &s; break; }
+        if (!slot) {
+            slot = &g_oneshot[g_oneshot_next];
+            g_oneshot_next = (g_oneshot_next + 1) % kOneShotSlots;
+            evicted = slot->plan;
+        }
+        slot->key = key;
+        slot->plan = plan;
+    }
+    if (evicted) (void)mi355_spmv_plan_destroy(evicted);
+}
+
+static void oneshot_release_all() {
+    mi355_spmv_plan* held[kOneShotSlots];
+    {
+        std::lock_guard<std::mutex> lock(g_oneshot_mutex);
+        for (int i = 0; i < kOneShotSlots; ++i) { held[i] = g_oneshot[i].plan; g_oneshot[i].plan = nullptr; }
+    }
+    for (mi355_spmv_plan* p : held)
+        if (p) (void)mi355_spmv_plan_destroy(p);
+}
+
+static OneShotKey key_of(const mi355_spmv_plan* h) {
+    const Plan& p = h->p;
+    return OneShotKey{h->acquired_on, p.kind, p.off_type, p.val_type, p.n_rows, p.n_cols, p.nnz, p.Ap, p.Aj};
+}
+
+// a kept plan for this matrix, or a new one
+static int plan_acquire(mi355_spmv_plan** out, int kind, int off_type, int val_type, int32_t n_rows, int32_t n_cols,
+                        int64_t nnz, const void* Ap, const int32_t* Aj) {
+    OneShotKey key{-1, kind, off_type, val_type, n_rows, n_cols, nnz, Ap, Aj};
+    const bool cache = oneshot_cache_enabled() && nnz > 0 && hipGetDevice(&key.device) == hipSuccess;
+    *out = cache ? oneshot_take(key) : nullptr;
+    if (*out) return MI355_SPMV_OK;
+    const int st = mi355_spmv_plan_create(out, kind, off_type, val_type, n_rows, n_cols, nnz, Ap, Aj, MI355_PLAN_DEFAULT);
+    if (st == MI355_SPMV_OK && cache) (*out)->acquired_on = key.device;
+    return st;
+}
+
+// give it back: kept for the next call on this matrix when that is safe (see above), destroyed otherwise.  The caller
+// has synchronised the stream the plan ran on.  ok = the execute succeeded.
+static int plan_release(mi355_spmv_plan* plan, bool ok) {
+    if (!plan) return MI355_SPMV_OK;
+    if (ok && plan->acquired_on >= 0 && plan->p.n_giant == 0 && plan->p.alpha == 1.0 && plan->p.beta == 0.0) {
+        oneshot_keep(key_of(plan), plan);
+        return MI355_SPMV_OK;
+    }
+    if (ok && plan->p.scratch) {          // ... or let at least its scratch serve the next call
+        retire_scratch(plan->p.scratch, plan->p.scratch_capacity);
+        plan->p.scratch = nullptr;
+    }
+    return mi355_spmv_plan_destroy(plan);
+}
+
 static int one_shot(int kind, int off_type, int val_type, int32_t n_rows, int32_t n_cols, int64_t nnz,
                     const void* Ap, const int32_t* Aj, const void* Ax, const void* x, void* y, void* stream,
                     int semiring = MI355_SEMIRING_PLUS_TIMES) {
     mi355_spmv_plan* plan = nullptr;
-    int st = mi355_spmv_plan_create(&plan, kind, off_type, val_type, n_rows, n_cols, nnz, Ap, Aj,
-                                    MI355_PLAN_DEFAULT);
+    int st = plan_acquire(&plan, kind, off_type, val_type, n_rows, n_cols, nnz, Ap, Aj);
     if (st != MI355_SPMV_OK) return st;
-    if (semiring != MI355_SEMIRING_PLUS_TIMES) {
+    if (semiring != plan->p.semiring) {
         st = mi355_spmv_plan_set_semiring(plan, semiring);
         if (st != MI355_SPMV_OK) { mi355_spmv_plan_destroy(plan); return st; }
     }
@@ -140,12 +241,7 @@ static int one_shot(int kind, int off_type, int val_type, int32_t n_rows, int32_
             st = MI355_SPMV_EHIP;
         }
     }
-    // the stream is synchronised: nothing can still touch the plan's scratch, it may serve the next call
-    if (st == MI355_SPMV_OK && plan->p.scratch) {
-        retire_scratch(plan->p.scratch, plan->p.scratch_capacity);
-        plan->p.scratch = nullptr;
-    }
-    const int st2 = mi355_spmv_plan_destroy(plan);
+    const int st2 = plan_release(plan, st == MI355_SPMV_OK);
     return st != MI355_SPMV_OK ? st : st2;
 }
 
@@ -379,6 +475,20 @@ int mi355_spmv_knobs_reload(void) {
     knobs_reload();
     return MI355_SPMV_OK;
 }
+
+int mi355_spmv_cache_release(void) {
+    oneshot_release_all();
+    return MI355_SPMV_OK;
+}
+
+int mi355_spmv_plan_acquire(mi355_spmv_plan** out, int kind, int off_type, int val_type, int32_t n_rows, int32_t n_cols,
+                            int64_t nnz, const void* Ap, const int32_t* Aj) {
+    g_err[0] = 0;
+    if (!out) { set_error("plan_acquire: null pointer"); return MI355_SPMV_EINVAL; }
+    return plan_acquire(out, kind, off_type, val_type, n_rows, n_cols, nnz, Ap, Aj);
+}
+
+int mi355_spmv_plan_release(mi355_spmv_plan* plan, int executed_ok) { return plan_release(plan, executed_ok != 0); }
 
 int mi355_spmv_plan_execute(mi355_spmv_plan* h, const void* Ax, const void* x, void* y, void* stream) {
     g_err[0] = 0;

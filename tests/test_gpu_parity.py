@@ -536,6 +536,56 @@ def test_band_wider_than_any_window_is_swept(sp, oracle, off, val, kind):
         assert torch.equal(y.view(torch.int32 if val == "f32" else torch.int64), y_blocks.view(torch.int32 if val == "f32" else torch.int64))
 
 
+@pytest.mark.parametrize("kind", KINDS)
+def test_one_shot_calls_keep_their_plan_and_survive_a_rewritten_matrix(sp, oracle, kind):
+    """The one-shot entry points find the plan of their previous call again by the pointers and sizes of Ap / Aj (the
+    reference's harness calls a kind 2 000 times in a row, main.cu:102-113).  A kept plan holds launch-shape decisions
+    only, so results must stay right when the caller REWRITES the arrays in place with another structure of the same
+    sizes — here a banded matrix turned into a scattered, ragged one with a hub row, same n_rows / nnz, same device
+    buffers — and again after mi355_spmv_cache_release()."""
+    rng = np.random.RandomState(123)
+    n, k = 40_000, 24
+    nnz = n * k
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    # structure 1: exactly k per row, narrow band
+    Ap1 = (np.arange(n + 1, dtype=np.int64) * k).astype(np.int32)
+    rows = np.repeat(np.arange(n), k)
+    Aj1 = np.clip(rows + rng.randint(-300, 301, size=nnz), 0, n - 1).astype(np.int32)
+    # structure 2: same sizes — ragged rows (many empty), scattered columns, one row of 60 000 nonzeros
+    lens = rng.multinomial(nnz - 60_000, np.ones(n - 1) / (n - 1))
+    lens = np.insert(lens, 777, 60_000)
+    Ap2 = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=Ap2[1:])
+    assert int(Ap2[-1]) == nnz
+    Ap2 = Ap2.astype(np.int32)
+    Aj2 = rng.randint(0, n, size=nnz).astype(np.int32)
+    Ax = (rng.rand(nnz) * 2 - 1).astype(np.float32)
+    x = (rng.rand(n) * 2 - 1).astype(np.float32)
+    dAp, dAj, dAx, dx = d(Ap1), d(Aj1), d(Ax), d(x)
+    sp.capi.cache_release()
+    y = torch.full((n,), float("nan"), device=DEV)
+    for _ in range(3):                                  # first call makes the plan, the next two find it again
+        y.fill_(float("nan"))
+        sp.spmv(kind, n, n, nnz, dAp, dAj, dAx, dx, y)
+        assert_parity(oracle, Ap1, Aj1, Ax, x, y.cpu().numpy())
+    dAp.copy_(d(Ap2))                                   # the same device buffers, another matrix
+    dAj.copy_(d(Aj2))
+    for _ in range(2):
+        y.fill_(float("nan"))
+        sp.spmv(kind, n, n, nnz, dAp, dAj, dAx, dx, y)
+        assert_parity(oracle, Ap2, Aj2, Ax, x, y.cpu().numpy())
+    sp.capi.cache_release()
+    y.fill_(float("nan"))
+    sp.spmv(kind, n, n, nnz, dAp, dAj, dAx, dx, y)      # a fresh plan for structure 2 (weight-cut chunks, long-row passes)
+    assert_parity(oracle, Ap2, Aj2, Ax, x, y.cpu().numpy())
+    dAp.copy_(d(Ap1))                                   # ... and back, under the plan made for structure 2
+    dAj.copy_(d(Aj1))
+    y.fill_(float("nan"))
+    sp.spmv(kind, n, n, nnz, dAp, dAj, dAx, dx, y)
+    assert_parity(oracle, Ap1, Aj1, Ax, x, y.cpu().numpy())
+    sp.capi.cache_release()
+
+
 # ---- BASELINE-sized inputs ---------------------------------------------------------------------
 
 @pytest.mark.parametrize("kind", KINDS)
