@@ -586,6 +586,48 @@ def test_one_shot_calls_keep_their_plan_and_survive_a_rewritten_matrix(sp, oracl
     sp.capi.cache_release()
 
 
+def test_one_shot_calls_from_several_threads_share_nothing(sp, oracle):
+    """Four host threads call the one-shot entry point on the SAME matrix at once, each on its own stream with its own y:
+    a kept plan is taken OUT of the cache by its user (its scratch serves one execute at a time), so a second thread
+    makes its own; every result must be right and every thread's results identical from call to call."""
+    import threading
+    rng = np.random.RandomState(5)
+    Ap, Aj, Ax = random_csr(rng, 50_000, 9000, 60, long_row=30_000)
+    x = (rng.rand(9000) * 2 - 1).astype(np.float32)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    dAp, dAj, dAx, dx = d(Ap), d(Aj), d(Ax), d(x)
+    nnz = int(Ap[-1])
+    sp.capi.cache_release()
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            kind = ("vector", "merge", "light", "merge")[tid]
+            outs = []
+            for _ in range(12):
+                y = torch.full((50_000,), float("nan"), device=DEV)
+                torch.cuda.current_stream().synchronize()     # (the poison is written on another stream than the SpMV's)
+                sp.spmv(kind, 50_000, 9000, nnz, dAp, dAj, dAx, dx, y, stream=stream)   # (synchronises its stream)
+                outs.append(y.cpu().numpy())
+            results[tid] = outs
+        except Exception as e:            # noqa: BLE001 (reported below)
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    sp.capi.cache_release()
+    assert not errors, errors
+    for tid, outs in results.items():
+        assert_parity(oracle, Ap, Aj, Ax, x, outs[0])
+        for o in outs[1:]:
+            assert np.array_equal(o, outs[0])
+
+
 # ---- BASELINE-sized inputs ---------------------------------------------------------------------
 
 @pytest.mark.parametrize("kind", KINDS)
