@@ -651,6 +651,14 @@ void shape_merge(Plan& p) {
         const int64_t mean1 = 1 + (p.n_rows > 0 ? (p.nnz - p.nnz_begin) / p.n_rows : 0);
         const int64_t rows_per_run = tps * p.tile_items / mean1 + 1;
         p.window_elems = (tps * p.tile_items >= 8192) ? pick_window_elems(p, rows_per_run) : 0;
+        // fp64 halves what the 36 KB budget (three workgroups per CU) holds: the S32-band shape in fp64 ran on plain
+        // gathers at 2.4 TB/s.  Second try with 56 KB (two workgroups per CU next to the kernel's 16-24 KB of own LDS).
+        if (p.window_elems == 0 && p.n_seg < 2 && p.val_type == MI355_VAL_F64 && p.knob.window < 0 && tps * p.tile_items >= 8192 &&
+            p.knob.merge_wide_window != 0) {
+            p.window_bytes = 56 * 1024;
+            p.window_elems = pick_window_elems(p, rows_per_run);
+            if (p.window_elems == 0 || p.n_seg >= 2) p.window_bytes = 0;
+        }
         several_bands = p.n_seg >= 2;
         if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }   // several bands: this kind keeps to global gathers
     }
@@ -758,20 +766,26 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
     const dim3 grid((unsigned)p.n_super);
 #define MI355_MERGE_ARGS dyn, s, p.n_rows, p.n_cols, p.nnz_begin, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_row, p.tile_nnz, p.tile_items, p.carry_row, \
                        static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super, cap, hint, (val_t)p.alpha, (val_t)p.beta
+#define MI355_MERGE_ALLOW(K_)                                                                                 \
+    if (dyn > 40 * 1024)                                                                                      \
+        if (const int st_ = allow_dynamic_lds((const void*)K_, dyn + 24 * 1024)) return st_;   /* (dynamic + the kernel's own LDS may pass 64 KB) */
 #define MI355_MERGE_LAUNCH(VEC_, WIN_, S_)                                                                    \
     do {                                                                                                      \
         if constexpr (S_ == MI355_SEMIRING_PLUS_TIMES) {                                                      \
             if (wide) {                                                                                       \
+                MI355_MERGE_ALLOW((merge_tile_kernel<kWideBlock, 4, VEC_, WIN_, S_, false, off_t, val_t, mat_t>)) \
                 hipLaunchKernelGGL((merge_tile_kernel<kWideBlock, 4, VEC_, WIN_, S_, false, off_t, val_t, mat_t>), grid, dim3(kWideBlock), MI355_MERGE_ARGS); \
                 break;                                                                                        \
             }                                                                                                 \
         }                                                                                                     \
         if constexpr (VEC_) {                                                                                 \
             if (fused) {                                                                                      \
+                MI355_MERGE_ALLOW((merge_tile_kernel<kBlock, 8, VEC_, WIN_, S_, true, off_t, val_t, mat_t>))  \
                 hipLaunchKernelGGL((merge_tile_kernel<kBlock, 8, VEC_, WIN_, S_, true, off_t, val_t, mat_t>), grid, dim3(kBlock), MI355_MERGE_ARGS); \
                 break;                                                                                        \
             }                                                                                                 \
         }                                                                                                     \
+        MI355_MERGE_ALLOW((merge_tile_kernel<kBlock, 8, VEC_, WIN_, S_, false, off_t, val_t, mat_t>))         \
         hipLaunchKernelGGL((merge_tile_kernel<kBlock, 8, VEC_, WIN_, S_, false, off_t, val_t, mat_t>), grid, dim3(kBlock), MI355_MERGE_ARGS); \
     } while (0)
 #define MI355_MERGE_SEMIRING(S_)                                                    \
@@ -799,6 +813,7 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
     }
 #undef MI355_MERGE_SEMIRING
 #undef MI355_MERGE_LAUNCH
+#undef MI355_MERGE_ALLOW
 #undef MI355_MERGE_ARGS
     return MI355_SPMV_OK;
 }
