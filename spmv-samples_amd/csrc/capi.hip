@@ -569,7 +569,7 @@ int mi355_spmv_plan_get_info(const mi355_spmv_plan* h, mi355_spmv_plan_info* inf
     info->kind = p.kind; info->off_type = p.off_type; info->val_type = p.val_type;
     info->lanes_per_row = p.lanes_per_row;
     info->elems_per_lane = p.elems_per_lane;
-    info->block_threads = p.block_threads > 0 ? p.block_threads : kBlock;
+    info->block_threads = (p.kind == MI355_KIND_MERGE && p.merge_rows) ? p.mr_block : (p.block_threads > 0 ? p.block_threads : kBlock);
     info->grid_blocks = p.grid_blocks;
     info->tile_items = p.tile_items;
     info->n_tiles = p.n_tiles;

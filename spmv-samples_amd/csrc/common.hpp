@@ -116,6 +116,8 @@ struct Plan {
     int window_bytes;           // LDS budget of the x window per workgroup (pick_window_elems)
     int window_elems;           // LDS window of x per workgroup, in elements; 0 = no window
     bool window_from_band;      // place the window from band_lo/band_hi instead of sampling per chunk
+    int mr_block = 256;         // MERGE, row-parallel runs: workgroup size (512: the band needs ~78 KB of LDS) and rows per piece of a run
+    int mr_piece_rows = 1984;
     bool sweep = false;         // VECTOR: the band is wider than any window — one group of rows per chunk, the window sweeps the band (chunk_rows_sweep)
     // multi-band plan: up to 4 bands of (column - row) found by clustering the probe's samples
     int n_seg;

@@ -483,16 +483,16 @@ constexpr int kMergeRowsCap = 1984;    // rows per piece: bounds + results fit 1
 // boundaries, found by the search kernel on n_super + 1 diagonals (every workgroup of a big grid would otherwise pay
 // the chain of dependent loads at its start).
 template <int BLOCK, int R, bool WINDOW, bool SEARCH, typename off_t, typename val_t>
-__global__ __launch_bounds__(BLOCK, 3) void merge_rows_kernel(
+__global__ __launch_bounds__(BLOCK, (BLOCK >= kWideBlock ? 4 : 3)) void merge_rows_kernel(
     int32_t n_rows, int32_t n_cols, int64_t nnz_begin, int64_t nnz, const off_t* __restrict__ Ap,
     const int32_t* __restrict__ Aj_arg, const val_t* __restrict__ Ax_arg, const val_t* __restrict__ x_arg,
     val_t* __restrict__ y_arg, int64_t tile_items, const int32_t* __restrict__ run_row, const int64_t* __restrict__ run_nnz,
     int32_t* __restrict__ carry_row, val_t* __restrict__ carry_val,
-    int64_t n_tiles, int32_t tiles_per_super, int32_t window_cap, BandHint hint, val_t alpha, val_t beta) {
+    int64_t n_tiles, int32_t tiles_per_super, int32_t window_cap, BandHint hint, val_t alpha, val_t beta, int32_t piece_rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2];
     __shared__ int64_t s_diag[4];            // (row, nnz) of the run's first and last diagonal
-    ChunkScratch<val_t> scr(s_dyn, window_cap, kMergeRowsCap);
+    ChunkScratch<val_t> scr(s_dyn, window_cap, piece_rows);
     scr.alpha = alpha;
     scr.beta = beta;
     const unsigned sup = xcd_contiguous_id(blockIdx.x, gridDim.x);
@@ -530,8 +530,8 @@ __global__ __launch_bounds__(BLOCK, 3) void merge_rows_kernel(
     const int64_t left = nnz - base;
     const int32_t nnz_c = int32_t(left < kRel32Limit ? left : kRel32Limit);
     val_t carry = val_t(0);
-    for (int64_t pb = 0; pb < n_all; pb += kMergeRowsCap) {          // (uniform; one piece unless the run holds > 1 984 rows)
-        const int64_t pe = min(pb + int64_t(kMergeRowsCap), n_all);
+    for (int64_t pb = 0; pb < n_all; pb += piece_rows) {             // (uniform; one piece unless the run holds more rows than the layout)
+        const int64_t pe = min(pb + int64_t(piece_rows), n_all);
         const int rows = int(pe - pb);
         // opaque copies of the operand pointers, once per piece (see light_rows.hip: keeps per-thread addresses from
         // being hoisted out of this loop and spilled)
@@ -667,6 +667,37 @@ void shape_merge(Plan& p) {
     // on plain gathers measured 720 us against 650-700 on the C4 stand-in, and with the bands staged per piece of a run
     // 681 against 727 on one box, with four spilling kernels: not kept)
     p.merge_rows = p.block_threads == kBlock && !several_bands && merge_rows_wanted(p);
+    p.mr_block = kBlock;
+    p.mr_piece_rows = kMergeRowsCap;
+    // The band does not fit the window of a 256-thread workgroup (fp64 on the S32-band shape: 8 193 columns + the rows of a run):
+    // two workgroups of 512 threads per CU may take ~78 KB each, as the CSR-vector kind's wide plan does; the run is then
+    // as long as the rows the band leaves room for, and walked in one piece.
+    if (p.merge_rows && p.knob.merge_wide_window != 0 && p.knob.window < 0 && p.knob.merge_tps <= 0 && p.probe_ok &&
+        !(p.window_elems > 0 && p.window_from_band)) {
+        const int64_t vb = p.val_type == MI355_VAL_F64 ? 8 : 4;
+        const int64_t band = p.band_hi - p.band_lo + 1;
+        int64_t piece = (78 * 1024 - vb * (band + 8) - 4) * 8 / (8 * (2 * vb + 4) + 1);   // val (band + rows + 8) + 4 (rows + 1) + val rows + rows / 8
+        piece &= ~int64_t(3);
+        if (piece > kMergeRowsCap) piece = kMergeRowsCap;
+        if (band > 0 && piece >= 256) {
+            const Plan saved = p;
+            const int64_t mean1 = 1 + (p.n_rows > 0 ? (p.nnz - p.nnz_begin) / p.n_rows : 0);
+            int64_t t2 = piece * mean1 / p.tile_items;
+            if (t2 > kMergeSuperItems / p.tile_items) t2 = kMergeSuperItems / p.tile_items;
+            if (t2 < 1) t2 = 1;
+            p.tiles_per_super = t2;
+            p.n_super = (p.n_tiles + t2 - 1) / t2;
+            p.grid_blocks = p.n_super;
+            p.window_bytes = int(vb * (band + piece + 8));
+            p.window_elems = pick_window_elems(p, piece);
+            if (p.window_elems > 0 && p.n_seg < 2 && p.window_from_band && p.n_super >= int64_t(kCus) * 2) {
+                p.mr_block = kWideBlock;
+                p.mr_piece_rows = int(piece);
+            } else {
+                p = saved;
+            }
+        }
+    }
     if (p.merge_rows) {
         p.n_kernels = (p.n_super > 1 ? 2 : 1) + (merge_search_in_kernel(p) ? 0 : 1);
         snprintf(p.main_kernel, sizeof(p.main_kernel), "merge_rows_kernel");
@@ -706,7 +737,7 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
         if (p.merge_rows && vec && p.semiring == MI355_SEMIRING_PLUS_TIMES) {
             constexpr int RR = sizeof(val_t) == 4 ? 4 : 2;
             const int32_t capw = (int32_t)p.window_elems;
-            const size_t lds = chunk_lds_bytes(capw, kMergeRowsCap, sizeof(val_t));
+            const size_t lds = chunk_lds_bytes(capw, p.mr_piece_rows, sizeof(val_t));
             const BandHint hint_r{p.band_lo, p.band_hi, p.window_from_band};
             const dim3 grid_r((unsigned)p.n_super);
             // run boundaries: searched in the kernel on small grids, by the search kernel (n_super + 1 diagonals of
@@ -720,16 +751,21 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
                 MI355_HIP_TRY(hipGetLastError());
                 p.coords_valid = false;       // (the arrays now hold RUN boundaries, not tile coordinates)
             }
-#define MI355_MERGE_ROWS_LAUNCH(WIN_, SEARCH_)                                                                     \
+            // (rows a vector keeps in flight: the 512-thread kernel is held to 128 VGPRs, which the fp32 body with 4 rows exceeds)
+#define MI355_MERGE_ROWS_LAUNCH(BLOCK_, WIN_, SEARCH_)                                                             \
     do {                                                                                                           \
-        if (const int st = allow_dynamic_lds((const void*)merge_rows_kernel<kBlock, RR, WIN_, SEARCH_, off_t, val_t>, lds)) return st; \
-        hipLaunchKernelGGL((merge_rows_kernel<kBlock, RR, WIN_, SEARCH_, off_t, val_t>), grid_r, dim3(kBlock), lds, s, p.n_rows, \
+        constexpr int RR_ = BLOCK_ >= kWideBlock ? 2 : RR;                                                          \
+        if (const int st = allow_dynamic_lds((const void*)merge_rows_kernel<BLOCK_, RR_, WIN_, SEARCH_, off_t, val_t>, lds + 1024)) return st; \
+        hipLaunchKernelGGL((merge_rows_kernel<BLOCK_, RR_, WIN_, SEARCH_, off_t, val_t>), grid_r, dim3(BLOCK_), lds, s, p.n_rows, \
                            p.n_cols, p.nnz_begin, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_items, p.tile_row, p.tile_nnz,   \
                            p.carry_row, static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super,    \
-                           capw, hint_r, (val_t)p.alpha, (val_t)p.beta);                                            \
+                           capw, hint_r, (val_t)p.alpha, (val_t)p.beta, (int32_t)p.mr_piece_rows);                  \
     } while (0)
-            if (capw > 0) { if (in_kernel) MI355_MERGE_ROWS_LAUNCH(true, true); else MI355_MERGE_ROWS_LAUNCH(true, false); }
-            else { if (in_kernel) MI355_MERGE_ROWS_LAUNCH(false, true); else MI355_MERGE_ROWS_LAUNCH(false, false); }
+            if (p.mr_block == kWideBlock && capw > 0) {       // (the wide run kernel exists around ONE window of x)
+                if (in_kernel) MI355_MERGE_ROWS_LAUNCH(kWideBlock, true, true); else MI355_MERGE_ROWS_LAUNCH(kWideBlock, true, false);
+            }
+            else if (capw > 0) { if (in_kernel) MI355_MERGE_ROWS_LAUNCH(kBlock, true, true); else MI355_MERGE_ROWS_LAUNCH(kBlock, true, false); }
+            else { if (in_kernel) MI355_MERGE_ROWS_LAUNCH(kBlock, false, true); else MI355_MERGE_ROWS_LAUNCH(kBlock, false, false); }
 #undef MI355_MERGE_ROWS_LAUNCH
             MI355_HIP_TRY(hipGetLastError());
             if (p.n_super > 1) {
