@@ -676,12 +676,16 @@ void shape_merge(Plan& p) {
         !(p.window_elems > 0 && p.window_from_band)) {
         const int64_t vb = p.val_type == MI355_VAL_F64 ? 8 : 4;
         const int64_t band = p.band_hi - p.band_lo + 1;
-        int64_t piece = (78 * 1024 - vb * (band + 8) - 4) * 8 / (8 * (2 * vb + 4) + 1);   // val (band + rows + 8) + 4 (rows + 1) + val rows + rows / 8
-        piece &= ~int64_t(3);
-        if (piece > kMergeRowsCap) piece = kMergeRowsCap;
-        if (band > 0 && piece >= 256) {
+        const int64_t mean1 = 1 + (p.n_rows > 0 ? (p.nnz - p.nnz_begin) / p.n_rows : 0);
+        // ... and a band too wide for that gets ONE workgroup of 1 024 threads per CU with ~155 KB (the CSR-vector kind's
+        // third plan): fp32, 32 769 columns, 32 per row: 343 -> see profiles/r02_shape_sweep.txt
+        const struct { int block; int64_t lds; int64_t min_piece; } tries[2] = {{kWideBlock, 78 * 1024, 256}, {kHugeBlock, 155 * 1024, 512}};
+        for (const auto& t : tries) {
+            int64_t piece = (t.lds - vb * (band + 8) - 4) * 8 / (8 * (2 * vb + 4) + 1);   // val (band + rows + 8) + 4 (rows + 1) + val rows + rows / 8
+            piece &= ~int64_t(3);
+            if (piece > kMergeRowsCap) piece = kMergeRowsCap;
+            if (!(band > 0 && piece >= t.min_piece)) continue;
             const Plan saved = p;
-            const int64_t mean1 = 1 + (p.n_rows > 0 ? (p.nnz - p.nnz_begin) / p.n_rows : 0);
             int64_t t2 = piece * mean1 / p.tile_items;
             if (t2 > kMergeSuperItems / p.tile_items) t2 = kMergeSuperItems / p.tile_items;
             if (t2 < 1) t2 = 1;
@@ -691,11 +695,11 @@ void shape_merge(Plan& p) {
             p.window_bytes = int(vb * (band + piece + 8));
             p.window_elems = pick_window_elems(p, piece);
             if (p.window_elems > 0 && p.n_seg < 2 && p.window_from_band && p.n_super >= int64_t(kCus) * 2) {
-                p.mr_block = kWideBlock;
+                p.mr_block = t.block;
                 p.mr_piece_rows = int(piece);
-            } else {
-                p = saved;
+                break;
             }
+            p = saved;
         }
     }
     if (p.merge_rows) {
@@ -761,7 +765,10 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
                            p.carry_row, static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super,    \
                            capw, hint_r, (val_t)p.alpha, (val_t)p.beta, (int32_t)p.mr_piece_rows);                  \
     } while (0)
-            if (p.mr_block == kWideBlock && capw > 0) {       // (the wide run kernel exists around ONE window of x)
+            if (p.mr_block == kHugeBlock && capw > 0) {       // (the wide run kernels exist around ONE window of x)
+                if (in_kernel) MI355_MERGE_ROWS_LAUNCH(kHugeBlock, true, true); else MI355_MERGE_ROWS_LAUNCH(kHugeBlock, true, false);
+            }
+            else if (p.mr_block == kWideBlock && capw > 0) {
                 if (in_kernel) MI355_MERGE_ROWS_LAUNCH(kWideBlock, true, true); else MI355_MERGE_ROWS_LAUNCH(kWideBlock, true, false);
             }
             else if (capw > 0) { if (in_kernel) MI355_MERGE_ROWS_LAUNCH(kBlock, true, true); else MI355_MERGE_ROWS_LAUNCH(kBlock, true, false); }

@@ -628,38 +628,42 @@ def test_one_shot_calls_from_several_threads_share_nothing(sp, oracle):
             assert np.array_equal(o, outs[0])
 
 
-@pytest.mark.parametrize("off", ["i32", "i64"])
-def test_merge_runs_in_fp64_take_the_wide_workgroup_when_the_band_needs_it(sp, oracle, off):
+@pytest.mark.parametrize("off,val,hw,block", [("i32", "f64", 4096, 512), ("i64", "f64", 4096, 512), ("i32", "f32", 16384, 1024),
+                                              ("i64", "f64", 8192, 1024)])
+def test_merge_runs_take_a_wide_workgroup_when_the_band_needs_it(sp, oracle, off, val, hw, block):
     """The S32-band shape in fp64: 8 193 columns of doubles + the rows of a run are more than a 256-thread workgroup's
     window holds (plain gathers: 718 us; a 56 KB window covering 78 %: 583), so the run kernel takes two workgroups of 512
-    threads per CU with ~78 KB each and runs as long as the band leaves room for (306 us).  Every row against the
-    bound, bitwise reproducible, alpha / beta, and the row-block form of the same matrix."""
+    threads per CU with ~78 KB each and runs as long as the band leaves room for (306 us); a wider band still gets ONE
+    workgroup of 1 024 threads with ~155 KB.  Every row against the bound, bitwise reproducible, alpha / beta."""
     n = 1_300_000
-    m = sp.synth.banded_fixed(n, 32, 4096, seed=8, device=DEV, val_dtype=torch.float64,
+    dt = torch.float64 if val == "f64" else torch.float32
+    m = sp.synth.banded_fixed(n, 32, hw, seed=8, device=DEV, val_dtype=dt,
                               off_dtype=torch.int32 if off == "i32" else torch.int64)
-    x = sp.synth.dense_vector(m.n_cols, torch.float64, 8, DEV)
-    p = sp.Plan("merge", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, torch.float64)
+    x = sp.synth.dense_vector(m.n_cols, dt, 8, DEV)
+    p = sp.Plan("merge", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, dt)
     info = p.info()
     if not any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB"):
-        assert info["main_kernel"] == "merge_rows_kernel" and info["block_threads"] == 512 and info["window_elems"] * 8 > 64 * 1024, info
-    y = torch.full((n,), float("nan"), dtype=torch.float64, device=DEV)
+        assert info["main_kernel"] == "merge_rows_kernel" and info["block_threads"] == block and \
+            info["window_elems"] * m.Ax.element_size() > 64 * 1024, info
+    y = torch.full((n,), float("nan"), dtype=dt, device=DEV)
     p.execute(m.Ax, x, y)
     torch.cuda.synchronize()
     Ap, Aj, Ax = m.numpy()
     assert_parity(oracle, Ap, Aj, Ax, x.cpu().numpy(), y.cpu().numpy())
-    y2 = torch.full((n,), float("nan"), dtype=torch.float64, device=DEV)
+    y2 = torch.full((n,), float("nan"), dtype=dt, device=DEV)
     p.execute(m.Ax, x, y2)
     torch.cuda.synchronize()
     assert torch.equal(y, y2)
     p.set_alpha_beta(-1.5, 0.5)
-    y0 = sp.synth.dense_vector(n, torch.float64, 9, DEV)
+    y0 = sp.synth.dense_vector(n, dt, 9, DEV)
     y3 = y0.clone()
     p.execute(m.Ax, x, y3)
     torch.cuda.synchronize()
     p.destroy()
     y64, bound = parity_bound(oracle, Ap, Aj, Ax, x.cpu().numpy(), 8)
-    want = -1.5 * y64 + 0.5 * y0.cpu().numpy()
-    assert np.all(np.abs(y3.cpu().numpy() - want) <= 1.5 * bound + 1e-15 * np.abs(want) + 1e-300)
+    want = -1.5 * y64 + 0.5 * y0.cpu().numpy().astype(np.float64)
+    eps = 2.0 ** -52 if val == "f64" else 2.0 ** -23
+    assert np.all(np.abs(y3.cpu().numpy().astype(np.float64) - want) <= 1.5 * bound + 4 * eps * (np.abs(want) + np.abs(y64) + 1.0) + 1e-300)
 
 
 # ---- BASELINE-sized inputs ---------------------------------------------------------------------
