@@ -367,40 +367,68 @@ int find_giant_rows(Plan& p) {
     p.n_giant_slices = 0;
     // (a row-block plan does what the whole matrix's plan decided: p.giant_enabled / p.giant_len are inherited)
     if (!p.balanced || (p.is_block ? !p.giant_enabled : p.knob.giant == 0)) { p.giant_enabled = false; return MI355_SPMV_OK; }
-    if (!p.is_block) p.giant_len = p.knob.giant_row >= 4096 ? p.knob.giant_row : kGiantRow;
+    // A row is giant when it alone is more than an eighth of a CU's fair share of the matrix (a hub of 30 K nonzeros in a
+    // 4 M-nonzero R-MAT kept ONE workgroup busy for most of the kernel: 75 us against merge's 30), between 4 K and 64 K.
+    if (!p.is_block) {
+        int64_t fair = ((p.nnz - p.nnz_begin) / (int64_t(kCus) * 8) + 1023) & ~int64_t(1023);
+        fair = fair < 4096 ? 4096 : (fair > kGiantRow ? kGiantRow : fair);
+        p.giant_len = p.knob.giant_row >= 4096 ? p.knob.giant_row : fair;
+    }
     p.giant_enabled = false;
     static_assert(1 + 2 * size_t(kMaxGiantRows) <= kAnalysisWords, "analysis buffer");
     std::lock_guard<std::mutex> lock(g_analysis_mutex);
     long long* buf = analysis_buffer();
     if (!buf) { set_error("find_giant_rows: no device scratch"); return MI355_SPMV_ENOMEM; }
-    hipError_t e = hipMemsetAsync(buf, 0, sizeof(long long), nullptr);
-    if (e == hipSuccess) {
-        const unsigned g = unsigned(std::min<int64_t>((int64_t(p.n_rows) + kBlock - 1) / kBlock, 2048));
-        if (p.off_type == MI355_OFF_I32)
-            hipLaunchKernelGGL((giant_scan_kernel<int32_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
-                               static_cast<const int32_t*>(p.Ap), kMaxGiantRows, p.giant_len, buf);
-        else
-            hipLaunchKernelGGL((giant_scan_kernel<int64_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
-                               static_cast<const int64_t*>(p.Ap), kMaxGiantRows, p.giant_len, buf);
-        e = hipGetLastError();
-    }
-    long long h[1 + 2 * kMaxGiantRows];
-    if (e == hipSuccess) e = hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost);   // synchronises
-    if (e != hipSuccess) {
-        set_error("find_giant_rows: %s", hipGetErrorString(e));
-        return MI355_SPMV_EHIP;
+    static thread_local long long h[1 + 2 * kMaxGiantRows];
+    auto scan = [&](int64_t giant_len) -> int {          // rows longer than giant_len -> h (count, then (row, length) pairs)
+        hipError_t e = hipMemsetAsync(buf, 0, sizeof(long long), nullptr);
+        if (e == hipSuccess) {
+            const unsigned g = unsigned(std::min<int64_t>((int64_t(p.n_rows) + kBlock - 1) / kBlock, 2048));
+            if (p.off_type == MI355_OFF_I32)
+                hipLaunchKernelGGL((giant_scan_kernel<int32_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
+                                   static_cast<const int32_t*>(p.Ap), kMaxGiantRows, giant_len, buf);
+            else
+                hipLaunchKernelGGL((giant_scan_kernel<int64_t>), dim3(g), dim3(kBlock), 0, nullptr, p.n_rows,
+                                   static_cast<const int64_t*>(p.Ap), kMaxGiantRows, giant_len, buf);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost);   // synchronises
+        if (e != hipSuccess) {
+            set_error("find_giant_rows: %s", hipGetErrorString(e));
+            return MI355_SPMV_EHIP;
+        }
+        return MI355_SPMV_OK;
+    };
+    if (const int st = scan(p.giant_len)) return st;
+    // The slices cost two more launches (~6 us).  With the threshold lowered for a small matrix they are only taken when the
+    // longest row is on the critical path by more than that: a workgroup walks ~1 K nonzeros of a hub per us, so the hub must
+    // outweigh a workgroup slot's share of the whole matrix (nonzeros + mean-row-length per row, over the slots in use) by 10 K+.
+    // R-MAT-18 (30 K hub, share 11 K): 75 -> 55 us; R-MAT-20 (69 K, 44 K): 200 -> 173; R-MAT-16 (13 K, 8 K) and the web-Google
+    // stand-in lost 6 us each with the slices and keep the default threshold.
+    if (!p.is_block && p.knob.giant_row < 4096 && p.giant_len < kGiantRow) {
+        long long longest = 0;
+        if (h[0] > 0 && h[0] <= kMaxGiantRows)
+            for (long long i = 0; i < h[0]; ++i) longest = std::max(longest, h[2 + 2 * i]);
+        const int64_t nnz = p.nnz - p.nnz_begin;
+        const int64_t slots = std::max<int64_t>(1, std::min<int64_t>(p.n_chunks, int64_t(kCus) * 3));   // (a small matrix has fewer chunks than slots)
+        const int64_t share = (nnz + (p.n_rows > 0 ? nnz / p.n_rows : 0) * int64_t(p.n_rows)) / slots;
+        if (longest < share + 10240) {
+            p.giant_len = kGiantRow;
+            if (const int st = scan(p.giant_len)) return st;
+        }
     }
     const long long count = h[0];
     if (count > kMaxGiantRows) return MI355_SPMV_OK;   // too many to be "a few dense rows": they stay with their workgroups
     p.giant_enabled = true;                            // (a block of this matrix may hold some even if this one holds none)
     if (count <= 0) return MI355_SPMV_OK;
-    std::pair<long long, long long> rows[kMaxGiantRows];
+    const int64_t slice = giant_slice_for(p.giant_len);
+    static thread_local std::pair<long long, long long> rows[kMaxGiantRows];
     for (long long i = 0; i < count; ++i) rows[i] = {h[1 + 2 * i], h[2 + 2 * i]};
     std::sort(rows, rows + count);                                // the device appended them in any order
     p.giant_slice_first_host[0] = 0;
     for (long long i = 0; i < count; ++i) {
         p.giant_row_host[i] = int32_t(rows[i].first);
-        p.giant_slice_first_host[i + 1] = p.giant_slice_first_host[i] + (rows[i].second + kGiantSlice - 1) / kGiantSlice;
+        p.giant_slice_first_host[i + 1] = p.giant_slice_first_host[i] + (rows[i].second + slice - 1) / slice;
     }
     p.n_giant = int(count);
     p.n_giant_slices = p.giant_slice_first_host[count];

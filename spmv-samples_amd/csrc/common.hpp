@@ -13,9 +13,16 @@ namespace mi355 {
 
 constexpr int kWave = 64;            // gfx950 wavefront width
 constexpr int kBlock = 256;          // 4 waves per workgroup
-constexpr int kMaxGiantRows = 256;    // giant rows a plan handles (more: they stay with their workgroup)
+constexpr int kMaxGiantRows = 1024;   // giant rows a plan handles (more: they stay with their workgroup)
 constexpr int64_t kGiantRow = 65536;   // a row beyond this many nonzeros is cut into slices of kGiantSlice
 constexpr int64_t kGiantSlice = 32768;
+// slice of a giant row when the plan's threshold is below the default (small power-law matrices: the threshold follows the
+// matrix, analyze.hip find_giant_rows): half the threshold, so that a row just beyond it is already shared by two workgroups
+inline int64_t giant_slice_for(int64_t giant_len) {
+    int64_t s = (giant_len / 2) & ~int64_t(1023);
+    if (s < 2048) s = 2048;
+    return s < kGiantSlice ? s : kGiantSlice;
+}
 constexpr int kWideBlock = 512;      // VECTOR / LIGHT on big uniform matrices: 8 waves, chunks twice as long
 constexpr int kHugeBlock = 1024;     // VECTOR, band too wide for two workgroups per CU: ONE 16-wave workgroup with ~150 KB of LDS
 constexpr int kSweepRows = 4;        // rows a vector of the sweep kernel holds (its whole chunk stays in registers)

@@ -4,7 +4,7 @@
 // row in an otherwise banded matrix) that workgroup streams alone while the chip idles (2^21 banded rows + one
 // row of 4 M entries: 5.8 ms, merge 0.33 ms).  Plans with weight-cut chunks therefore list such rows at
 // creation (find_giant_rows, analyze.hip); the chunk kernel stores 0 for them, and two small kernels follow:
-//   giant_slices_kernel   one workgroup per slice of kGiantSlice nonzeros: partial sum -> scratch
+//   giant_slices_kernel   one workgroup per slice of giant_slice_for(giant_len) nonzeros: partial sum -> scratch
 //   giant_final_kernel    one thread per giant row: adds the row's partials IN SLICE ORDER into y
 // so the result does not depend on which workgroup finishes first (no float atomics: run-to-run bitwise
 // reproducible like everything else here).  The reference's row-based kernels have no counterpart: a long
@@ -20,7 +20,7 @@ template <typename off_t, typename val_t>
 __global__ __launch_bounds__(kBlock) void giant_slices_kernel(
     int n_giant, const int32_t* __restrict__ giant_row, const int64_t* __restrict__ slice_first,
     const off_t* __restrict__ Ap, const int32_t* __restrict__ Aj, const val_t* __restrict__ Ax,
-    const val_t* __restrict__ x, val_t* __restrict__ partial) {
+    const val_t* __restrict__ x, val_t* __restrict__ partial, int64_t slice_len) {
     __shared__ val_t s_part[kBlock / kWave];
     const int64_t slice = blockIdx.x;
     int lo = 0, hi = n_giant;                    // the giant row this slice belongs to: last g with slice_first[g] <= slice
@@ -30,9 +30,9 @@ __global__ __launch_bounds__(kBlock) void giant_slices_kernel(
         else hi = mid;
     }
     const int32_t row = giant_row[lo];
-    const int64_t begin = int64_t(Ap[row]) + (slice - slice_first[lo]) * kGiantSlice;
+    const int64_t begin = int64_t(Ap[row]) + (slice - slice_first[lo]) * slice_len;
     const int64_t row_end = int64_t(Ap[row + 1]);
-    const int64_t end = begin + kGiantSlice < row_end ? begin + kGiantSlice : row_end;
+    const int64_t end = begin + slice_len < row_end ? begin + slice_len : row_end;
     val_t sum = val_t(0);
     // 4 independent loads per thread per trip; the columns of such a row are all over x: plain gathers
     for (int64_t k = begin + threadIdx.x; k < end; k += int64_t(kBlock) * 4) {
@@ -77,7 +77,7 @@ static int launch_giant_rows(const Plan& p, const off_t* Ap, const val_t* Ax, co
     if (p.n_giant <= 0) return MI355_SPMV_OK;
     hipLaunchKernelGGL((giant_slices_kernel<off_t, val_t>), dim3((unsigned)p.n_giant_slices), dim3(kBlock), 0, s,
                        p.n_giant, p.giant_row, p.giant_slice_first, Ap, p.Aj, Ax, x,
-                       static_cast<val_t*>(p.giant_partial));
+                       static_cast<val_t*>(p.giant_partial), giant_slice_for(p.giant_len));
     MI355_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL((giant_final_kernel<val_t>), dim3((unsigned)((p.n_giant + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
                        p.n_giant, p.giant_row, p.giant_slice_first, static_cast<const val_t*>(p.giant_partial), y,
