@@ -9,7 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "spmv-samples_amd", "csrc")
-TUS = ["csr_vector.hip", "csr_vector_f64.hip", "light_rows.hip", "light_rows_f64.hip", "merge_path.hip", "analyze.hip",
+TUS = ["csr_vector.hip", "csr_vector_f64.hip", "light_rows.hip", "light_rows_f64.hip", "merge_path.hip", "merge_path_f64.hip",
+       "merge_path_i32.hip", "analyze.hip",
        "dist.hip"]
 
 

@@ -616,7 +616,7 @@ static bool merge_search_in_kernel(const Plan& p) {
 // 64: 205 / 245, 100: 229 / 242, 128: 195 / 237 — but 40: 262 / 256 (a step of 64 is 62 % full), and rows of VARYING length
 // lose at every mean (24 +- 6: 415 / 341, 64 +- 16: 479 / 381, 128 +- 32: 502 / 380): those keep the item walk, at
 // 4.8-5.5 TB/s.  MI355_MERGE_ROWS = 0 | 1 overrides.
-static bool merge_rows_wanted(const Plan& p) {
+[[maybe_unused]] static bool merge_rows_wanted(const Plan& p) {
     if (p.knob.merge_rows >= 0) return p.knob.merge_rows != 0;
     if (!p.probe_ok || p.n_rows <= 0 || p.val_type == MI355_VAL_I32) return false;
     if (p.tiles_per_super * p.tile_items < 16384) return false;
@@ -625,6 +625,7 @@ static bool merge_rows_wanted(const Plan& p) {
     return false;
 }
 
+#if !defined(MI355_TU_F64) && !defined(MI355_TU_I32)   // the host-side shape functions live in the fp32 translation unit only
 void shape_merge(Plan& p) {
     // tuning knobs: MI355_MERGE_TPS = tiles per run (and MI355_SPMV_WINDOW = 0|1, analyze.hip)
     // 256 threads x 8 items or (MI355_MERGE_BLOCK=512) 512 threads x 4 items: the same 2 044-item tiles
@@ -726,6 +727,8 @@ int merge_compute_coords(Plan& p) {
     MI355_HIP_TRY(hipStreamSynchronize(nullptr));
     return MI355_SPMV_OK;
 }
+
+#endif
 
 template <typename off_t, typename val_t, typename mat_t>
 int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_t* y, hipStream_t s) {
@@ -861,15 +864,21 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
     return MI355_SPMV_OK;
 }
 
-template int launch_merge<int32_t, float, float>(Plan&, const int32_t*, const float*, const float*, float*, hipStream_t);
+// One translation unit per value type (merge_path_f64.hip / merge_path_i32.hip include this file with MI355_TU_F64 /
+// MI355_TU_I32): the three thirds of the instantiations compile side by side.
+#if defined(MI355_TU_F64)
 template int launch_merge<int32_t, double, double>(Plan&, const int32_t*, const double*, const double*, double*, hipStream_t);
-template int launch_merge<int64_t, float, float>(Plan&, const int64_t*, const float*, const float*, float*, hipStream_t);
 template int launch_merge<int64_t, double, double>(Plan&, const int64_t*, const double*, const double*, double*, hipStream_t);
 // fp32 matrix under fp64 vectors (mi355_spmv_plan_create_typed)
 template int launch_merge<int32_t, double, float>(Plan&, const int32_t*, const float*, const double*, double*, hipStream_t);
 template int launch_merge<int64_t, double, float>(Plan&, const int64_t*, const float*, const double*, double*, hipStream_t);
+#elif defined(MI355_TU_I32)
 // 32-bit integer values (MI355_VAL_I32: every semiring, exact)
 template int launch_merge<int32_t, int32_t, int32_t>(Plan&, const int32_t*, const int32_t*, const int32_t*, int32_t*, hipStream_t);
 template int launch_merge<int64_t, int32_t, int32_t>(Plan&, const int64_t*, const int32_t*, const int32_t*, int32_t*, hipStream_t);
+#else
+template int launch_merge<int32_t, float, float>(Plan&, const int32_t*, const float*, const float*, float*, hipStream_t);
+template int launch_merge<int64_t, float, float>(Plan&, const int64_t*, const float*, const float*, float*, hipStream_t);
+#endif
 
 }  // namespace mi355
