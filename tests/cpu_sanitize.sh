@@ -4,7 +4,7 @@
 # (The loader's exception tests are left out: a preloaded ASan cannot intercept __cxa_throw from a library loaded later —
 #  "CHECK failed: real___cxa_throw != 0" is the tool's, not a finding.)  Restores the normal builds afterwards.
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/.."   # (repo root)
 FLAGS="-std=c++17 -O1 -g -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -Wall -Wextra"
 cp oracle/liboracle.so /tmp/liboracle.so.bak; cp tests/cpp/libhostload.so /tmp/libhostload.so.bak 2>/dev/null || true
 trap 'cp /tmp/liboracle.so.bak oracle/liboracle.so; [ -f /tmp/libhostload.so.bak ] && cp /tmp/libhostload.so.bak tests/cpp/libhostload.so' EXIT
