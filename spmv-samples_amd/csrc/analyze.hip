@@ -62,6 +62,7 @@ static void parse_knobs(Knobs& k) {
     geti("MI355_MERGE_SEARCH_LANES", k.merge_search_lanes);
     geti("MI355_MERGE_FUSED", k.merge_fused);
     geti("MI355_MERGE_WIDE_WINDOW", k.merge_wide_window);
+    geti("MI355_SPMV_PLAN_CACHE", k.plan_cache);
     geti("MI355_MERGE_ROWS", k.merge_rows);
     if (k.window > 1) k.window = 1;
     if (k.balance > 1) k.balance = 1;

@@ -147,10 +147,7 @@ static std::mutex g_oneshot_mutex;
 static OneShotSlot g_oneshot[kOneShotSlots];
 static int g_oneshot_next = 0;
 
-static bool oneshot_cache_enabled() {
-    static const bool on = [] { const char* e = getenv("MI355_SPMV_PLAN_CACHE"); return !(e && e[0] == '0'); }();
-    return on;
-}
+static bool oneshot_cache_enabled() { return knobs().plan_cache != 0; }
 
 static mi355_spmv_plan* oneshot_take(const OneShotKey& key) {
     std::lock_guard<std::mutex> lock(g_oneshot_mutex);

@@ -78,6 +78,7 @@ struct Knobs {
     int merge_search_lanes = 0;// MI355_MERGE_SEARCH_LANES    1 | 4 | 16
     int merge_rows = -1;       // MI355_MERGE_ROWS            0 = never the row-parallel run kernel, 1 = always
     int merge_fused = -1;      // MI355_MERGE_FUSED           0 = never the single-launch small-grid kernel, 1 = whenever legal
+    int plan_cache = -1;       // MI355_SPMV_PLAN_CACHE       0 = the one-shot entry points make and destroy a plan per call
     int merge_wide_window = -1;// MI355_MERGE_WIDE_WINDOW     0 = fp64 keeps the 36 KB window budget (no second try with 56 KB)
     char text[160] = "";       // the non-default ones, "NAME=value ..." (as read)
 };
