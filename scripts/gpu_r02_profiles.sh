@@ -10,7 +10,7 @@ rm -rf $O; mkdir -p $O
 cd /tmp
 trace() {
   local tag=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$tag -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline "$@" > $O/trace_$tag.json 2> $O/trace_$tag.err || { echo "trace $tag failed"; tail -3 $O/trace_$tag.err; }
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$tag -- python3 $R/bench.py --steps 100 --warmup 50 --no-cpu-baseline "$@" > $O/trace_$tag.json 2> $O/trace_$tag.err || { echo "trace $tag failed"; tail -3 $O/trace_$tag.err; }
 }
 pmc() {
   local tag=$1 ctr="$2"; shift; shift

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise every rocprofv3 output directory under <dir>: trace_* -> mean / min / median duration per
-kernel, pmc_* -> mean counter value per launch and kernel.  Prints one JSON object."""
+kernel (steady state: the last two thirds of the launches; mean_all_us: all of them), pmc_* -> mean counter value per launch
+and kernel.  Prints one JSON object."""
 import csv
 import glob
 import json
@@ -35,8 +36,13 @@ for d in sorted(glob.glob(os.path.join(root, "trace_*"))):
         k = short(row["Kernel_Name"])
         if k:
             dur[k].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
-    out[os.path.basename(d)] = {k: {"launches": len(v), "mean_us": sum(v) / len(v), "min_us": min(v),
-                                    "median_us": statistics.median(v)} for k, v in dur.items()}
+    # mean_us: over the last two thirds of the launches (in trace order) — an HBM-bound kernel runs its first ~60 executes
+    # from a fresh plan 5-10 % slower (profiles/r02_warmup_curve.txt); mean_all_us: every launch
+    def stats(v):
+        w = v[len(v) // 3:] if len(v) >= 6 else v
+        return {"launches": len(v), "mean_us": sum(w) / len(w), "mean_all_us": sum(v) / len(v), "min_us": min(v),
+                "median_us": statistics.median(w)}
+    out[os.path.basename(d)] = {k: stats(v) for k, v in dur.items()}
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(d):
         continue
