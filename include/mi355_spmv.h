@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI355_SPMV_VERSION 200 /* 0.2.0 */
+#define MI355_SPMV_VERSION 300 /* 0.3.0 */
 
 /* status codes */
 enum {
@@ -278,6 +278,49 @@ int mi355_spmv_dist_create_rank(mi355_spmv_dist** dist, int kind, int off_type, 
 int mi355_spmv_dist_scatter_values(mi355_spmv_dist* dist, const void* Ax, void* stream);
 int mi355_spmv_dist_replicate_x(mi355_spmv_dist* dist, const void* x, void* stream);
 int mi355_spmv_dist_execute(mi355_spmv_dist* dist, const void* Ax, const void* x, void* y, void* stream);
+/* The same with flags, so that a scaling report can tell compute from exchange (north star: "1/2/4/8-GPU GFLOP/s and
+ * bandwidth-fraction scaling reported"; SURVEY §8(e): "report compute-only and end-to-end scaling"):
+ *   MI355_DIST_EXEC_SKIP_EXCHANGE   the blocks' kernels with the whole stream choreography, no RCCL call: afterwards
+ *                                   every GPU holds ITS rows of y only;
+ *   MI355_DIST_EXEC_EXCHANGE_ONLY   no kernel: the allgatherv of whatever y holds.
+ * Collective like execute: every rank / GPU passes the same flags.                                                   */
+enum { MI355_DIST_EXEC_DEFAULT = 0, MI355_DIST_EXEC_SKIP_EXCHANGE = 1, MI355_DIST_EXEC_EXCHANGE_ONLY = 2 };
+int mi355_spmv_dist_execute_ex(mi355_spmv_dist* dist, const void* Ax, const void* x, void* y, void* stream,
+                               int exec_flags);
+/* How the y slices travel.  RCCL has no allgatherv (SURVEY §5 last row names three ways to make one); all three are
+ * built behind this one API, per sub-block s, on the communication stream:
+ *   BCAST      one group of in-place ncclBroadcast, root = owner of block (root, s): a ring per root;
+ *   SENDRECV   one group of ncclSend / ncclRecv, every GPU sends its block to every peer and receives theirs:
+ *              point to point, all xGMI links at once;
+ *   ALLGATHER  one ncclAllGather: in place in y when the blocks of sub-block s are equal and adjacent (one block per
+ *              GPU on a uniform matrix), else through a staging buffer padded to the largest block (one pack and
+ *              one unpack kernel around it).
+ * AUTO (default, or MI355_DIST_EXCHANGE=auto): when more than one GPU takes part, create times MI355_DIST_TRIALS (5)
+ * exchanges of each on scratch buffers, agrees on the maximum over ranks (ncclAllReduce) and keeps the fastest;
+ * dist_get_info reports the choice and the trial times.  set_exchange changes it later (collective: every rank the
+ * same value, no execute in flight).                                                                               */
+enum { MI355_DIST_EXCHANGE_AUTO = 0, MI355_DIST_EXCHANGE_BCAST = 1, MI355_DIST_EXCHANGE_SENDRECV = 2,
+       MI355_DIST_EXCHANGE_ALLGATHER = 3, MI355_DIST_EXCHANGE_COUNT = 4 };
+int mi355_spmv_dist_set_exchange(mi355_spmv_dist* dist, int exchange);
+typedef struct mi355_spmv_dist_info {
+    int32_t world, rank, sub_blocks, local_mode;
+    int32_t exchange;          /* MI355_DIST_EXCHANGE_* in use (never AUTO; BCAST when world == 1: unused)        */
+    int32_t auto_picked;       /* 1 = chosen by the timed trial at create                                        */
+    int32_t allgather_in_place;/* 1 = every sub-block's ALLGATHER goes straight into y (no staging)              */
+    int32_t reserved0;
+    float trial_us[MI355_DIST_EXCHANGE_COUNT];   /* per exchange of all sub-blocks, max over ranks; 0 = not timed */
+    int64_t max_block_rows;    /* largest block (the padded count of ALLGATHER)                                  */
+    int64_t staging_bytes;     /* per GPU, ALLGATHER through staging                                             */
+    char exchange_name[16];
+} mi355_spmv_dist_info;
+int mi355_spmv_dist_get_info(const mi355_spmv_dist* dist, mi355_spmv_dist_info* info);
+/* A dist handle holds COPIES of the structure (a rebased Ap per block; Aj on the other GPUs), so unlike the one-shot
+ * plan cache it is wrong for a matrix rewritten in place.  For callers with the reference's semantics — SpMV(kind,
+ * ...) reads its arrays on every call — this compares a fingerprint of the caller's Ap (every offset) and Aj (a
+ * strided sample of 64 K entries) with the one taken at create: one small kernel and one 16-byte read-back
+ * (synchronises `stream`).  LOCAL mode only.  *changed = 1: destroy the handle and create it again.             */
+int mi355_spmv_dist_structure_changed(mi355_spmv_dist* dist, const void* Ap, const int32_t* Aj, void* stream,
+                                      int* changed);
 int mi355_spmv_dist_set_alpha_beta(mi355_spmv_dist* dist, double alpha, double beta);
 /* number of blocks, and the global cut rows (parts + 1 entries)                */
 int mi355_spmv_dist_parts(const mi355_spmv_dist* dist);

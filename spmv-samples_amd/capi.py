@@ -35,7 +35,8 @@ EXPORTS = (
        "mi355_spmv_plan_create_typed", "mi355_spmv_merge_f32mat_f64vec_i32",
        "mi355_spmv_merge_f32mat_f64vec_i64"]
     + ["mi355_spmv_dist_" + n for n in ("create_local", "unique_id", "create_rank", "scatter_values", "replicate_x",
-                                        "execute", "set_alpha_beta", "parts", "cuts", "part_info", "device_y", "device_x",
+                                        "execute", "execute_ex", "set_exchange", "get_info", "structure_changed",
+                                        "set_alpha_beta", "parts", "cuts", "part_info", "device_y", "device_x",
                                         "destroy")]
 )
 
@@ -69,6 +70,16 @@ class PlanShape(C.Structure):
                 ("band_lo", C.c_int64), ("band_hi", C.c_int64), ("seg_lo", C.c_int64 * 4), ("seg_hi", C.c_int64 * 4),
                 ("window_sweep", C.c_int32), ("reserved0", C.c_int32)]
 
+
+class DistInfo(C.Structure):
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("sub_blocks", C.c_int32), ("local_mode", C.c_int32),
+                ("exchange", C.c_int32), ("auto_picked", C.c_int32), ("allgather_in_place", C.c_int32),
+                ("reserved0", C.c_int32), ("trial_us", C.c_float * 4), ("max_block_rows", C.c_int64),
+                ("staging_bytes", C.c_int64), ("exchange_name", C.c_char * 16)]
+
+
+EXCHANGES = {"auto": 0, "bcast": 1, "sendrecv": 2, "allgather": 3}
+EXEC_DEFAULT, EXEC_SKIP_EXCHANGE, EXEC_EXCHANGE_ONLY = 0, 1, 2
 
 _lib = None
 
@@ -109,6 +120,11 @@ def lib():
         L.mi355_spmv_dist_scatter_values.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi355_spmv_dist_replicate_x.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi355_spmv_dist_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi355_spmv_dist_execute_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.mi355_spmv_dist_set_exchange.argtypes = [C.c_void_p, C.c_int]
+        L.mi355_spmv_dist_get_info.argtypes = [C.c_void_p, C.POINTER(DistInfo)]
+        L.mi355_spmv_dist_structure_changed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                        C.POINTER(C.c_int)]
         L.mi355_spmv_dist_set_alpha_beta.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.mi355_spmv_dist_parts.argtypes = [C.c_void_p]
         L.mi355_spmv_dist_cuts.argtypes = [C.c_void_p, C.c_void_p]
@@ -401,9 +417,10 @@ class DistPlan:
         _check(lib().mi355_spmv_dist_replicate_x(self._h, C.c_void_p(x.data_ptr()), _stream_ptr(stream)),
                "mi355_spmv_dist_replicate_x")
 
-    def execute(self, Ax, x, y, stream=None):
+    def execute(self, Ax, x, y, stream=None, flags=EXEC_DEFAULT):
         """Asynchronous on `stream`.  LOCAL: home-device Ax / x (None = unchanged since scatter_values /
-        replicate_x) and the full y; RANK: this rank's values view, its x, its full-length y."""
+        replicate_x) and the full y; RANK: this rank's values view, its x, its full-length y.
+        flags: EXEC_SKIP_EXCHANGE (kernels only) / EXEC_EXCHANGE_ONLY (the allgatherv of whatever y holds)."""
         for t in (Ax, x, y):
             if t is not None:
                 _require_device(t)
@@ -413,9 +430,31 @@ class DistPlan:
             raise ValueError("y is shorter than the matrix has rows")
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         with torch.cuda.device(y.device):
-            st = lib().mi355_spmv_dist_execute(self._h, p(Ax), p(x), p(y), _stream_ptr(stream))
-        _check(st, "mi355_spmv_dist_execute")
+            st = lib().mi355_spmv_dist_execute_ex(self._h, p(Ax), p(x), p(y), _stream_ptr(stream), flags)
+        _check(st, "mi355_spmv_dist_execute_ex")
         return y
+
+    def set_exchange(self, name):
+        """'bcast' | 'sendrecv' | 'allgather' (collective: every rank the same)."""
+        _check(lib().mi355_spmv_dist_set_exchange(self._h, EXCHANGES[name]), "mi355_spmv_dist_set_exchange")
+
+    def dist_info(self):
+        di = DistInfo()
+        _check(lib().mi355_spmv_dist_get_info(self._h, C.byref(di)), "mi355_spmv_dist_get_info")
+        d = {n: getattr(di, n) for n, _ in di._fields_ if n not in ("trial_us", "exchange_name", "reserved0")}
+        d["exchange_name"] = di.exchange_name.decode()
+        d["trial_us"] = {k: float(di.trial_us[v]) for k, v in EXCHANGES.items() if v}
+        return d
+
+    def structure_changed(self, Ap, Aj, stream=None):
+        """LOCAL mode: does the caller's Ap / Aj still match the fingerprint taken at create?"""
+        _require_device(Ap, Aj)
+        out = C.c_int(0)
+        with torch.cuda.device(Ap.device):
+            st = lib().mi355_spmv_dist_structure_changed(self._h, C.c_void_p(Ap.data_ptr()), C.c_void_p(Aj.data_ptr()),
+                                                         _stream_ptr(stream), C.byref(out))
+        _check(st, "mi355_spmv_dist_structure_changed")
+        return bool(out.value)
 
     def set_alpha_beta(self, alpha, beta):
         _check(lib().mi355_spmv_dist_set_alpha_beta(self._h, C.c_double(alpha), C.c_double(beta)),

@@ -64,6 +64,17 @@ static void parse_knobs(Knobs& k) {
     geti("MI355_MERGE_WIDE_WINDOW", k.merge_wide_window);
     geti("MI355_SPMV_PLAN_CACHE", k.plan_cache);
     geti("MI355_MERGE_ROWS", k.merge_rows);
+    geti("MI355_DIST_TRIALS", k.dist_trials);
+    geti("MI355_DIST_SHARED_DEVICE", k.dist_shared_device);
+    if (const char* v = getenv("MI355_DIST_EXCHANGE")) {
+        k.dist_exchange = !strcmp(v, "bcast") ? MI355_DIST_EXCHANGE_BCAST : !strcmp(v, "sendrecv") ? MI355_DIST_EXCHANGE_SENDRECV
+                          : !strcmp(v, "allgather") ? MI355_DIST_EXCHANGE_ALLGATHER : MI355_DIST_EXCHANGE_AUTO;
+        note("MI355_DIST_EXCHANGE", v);
+    }
+    if (const char* v = getenv("MI355_SPMV_RCCL_LIB")) {
+        snprintf(k.rccl_lib, sizeof(k.rccl_lib), "%s", v);
+        note("MI355_SPMV_RCCL_LIB", strrchr(v, '/') ? strrchr(v, '/') + 1 : v);
+    }
     if (k.window > 1) k.window = 1;
     if (k.balance > 1) k.balance = 1;
 }

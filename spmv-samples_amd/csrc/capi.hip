@@ -2,6 +2,7 @@
 // Plan life cycle, argument checks, type dispatch.  No CPU compute path exists
 // in this library: every entry point either launches HIP kernels or fails.
 
+#include <algorithm>
 #include <cstdarg>
 #include <mutex>
 #include <new>
@@ -336,7 +337,10 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
             return MI355_SPMV_EINVAL;
         }
         p.is_block = true;
-        if ((blk->nnz_begin_whole & ~int64_t(3)) + nnz < w->nnz) p.nnz_read = (nnz + 3) & ~int64_t(3);   // not the last block
+        // not the last block: the tail of its last row is read in whole 16-byte groups, as the whole plan reads it — but
+        // never past the end of the whole arrays (a block that ends inside their last, partial group)
+        if ((blk->nnz_begin_whole & ~int64_t(3)) + nnz < w->nnz)
+            p.nnz_read = std::min((nnz + 3) & ~int64_t(3), w->nnz - (blk->nnz_begin_whole & ~int64_t(3)));
         p.block_row_begin = blk->row_begin;
         p.block_chunk_begin = blk->chunk_begin;
         p.lanes_per_row = w->lanes_per_row;
@@ -470,6 +474,7 @@ int mi355_spmv_plan_partition(const mi355_spmv_plan* h, int parts, int64_t* row_
 
 int mi355_spmv_knobs_reload(void) {
     knobs_reload();
+    oneshot_release_all();     // (the kept one-shot plans were shaped under the old knobs)
     return MI355_SPMV_OK;
 }
 

@@ -80,6 +80,10 @@ struct Knobs {
     int merge_fused = -1;      // MI355_MERGE_FUSED           0 = never the single-launch small-grid kernel, 1 = whenever legal
     int plan_cache = -1;       // MI355_SPMV_PLAN_CACHE       0 = the one-shot entry points make and destroy a plan per call
     int merge_wide_window = -1;// MI355_MERGE_WIDE_WINDOW     0 = fp64 keeps the 36 KB window budget (no second try with 56 KB)
+    int dist_exchange = 0;     // MI355_DIST_EXCHANGE         auto | bcast | sendrecv | allgather (MI355_DIST_EXCHANGE_*; auto = timed trial at create)
+    int dist_trials = 0;       // MI355_DIST_TRIALS           exchanges timed per candidate by the auto pick (default 5)
+    int dist_shared_device = 0;// MI355_DIST_SHARED_DEVICE    tests: 1 = a device may be listed twice (an emulated RCCL: several "GPUs" on one)
+    char rccl_lib[200] = "";   // MI355_SPMV_RCCL_LIB         the RCCL to dlopen instead of librccl.so.1 (tests: tests/cpp/libfakerccl.so)
     char text[160] = "";       // the non-default ones, "NAME=value ..." (as read)
 };
 const Knobs& knobs();          // parsed on first use

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(sp):
 
 def test_version_and_status_strings(sp):
     lib = sp.capi.lib()
-    assert lib.mi355_spmv_version() == 200
+    assert lib.mi355_spmv_version() == 300
     assert lib.mi355_spmv_status_string(0) == b"ok"
     assert lib.mi355_spmv_status_string(1) == b"invalid argument"
     assert lib.mi355_spmv_status_string(99) == b"unknown status"
