@@ -2,6 +2,7 @@
 """bench.py — CSR SpMV throughput on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s32-band] [--kind auto]
+    python bench.py --mtx FILE.mtx [--dtype f32|f64] [--offset 32|64]        # a Matrix Market file (main.cu:32-39)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one SpMV  y = A x  through the C ABI (mi355_spmv_plan_execute: every kernel of
@@ -9,13 +10,17 @@ the kind runs every step; the plan only holds scratch and launch shapes), inputs
 resident in HBM.  N > 1: one process per GPU — `python bench.py --gpus N` starts its N
 rank processes itself (fresh children, before anything here touches a GPU), or the
 driver starts them with torch.distributed.run — the matrix is row-sharded (each rank
-holds 2^22 rows of a banded matrix with N*2^22 rows: weak scaling; --workload c5-rmat24
-cuts ONE R-MAT-24 matrix into N nnz-balanced row blocks: strong scaling), x is
-replicated and every step ends with the allgatherv of the y slices over RCCL, made by the
-library itself (mi355_spmv_dist_*: grouped in-place ncclBroadcasts on a communication
-stream, each GPU's rows in sub-blocks so that a slice travels while the next is computed;
-SURVEY.md §8(e)).  torch.distributed (gloo) only carries the control plane: the 128-byte
-RCCL id, the barriers and the max-over-ranks of the timing.
+holds 2^22 rows of a banded matrix with N*2^22 rows: weak scaling; any other workload,
+e.g. --workload c5-rmat24 or --mtx, cuts ONE matrix into N nnz-balanced row blocks:
+strong scaling), x is replicated and every step ends with the allgatherv of the y slices
+over RCCL, made by the library itself (mi355_spmv_dist_*: grouped broadcasts, send/recv
+pairs or one all-gather per sub-block on a communication stream — the library times the
+three when the communicator comes up and keeps the fastest — each GPU's rows in
+sub-blocks so that a slice travels while the next is computed).
+torch.distributed (gloo) only carries the control plane: the 128-byte RCCL id, the
+barriers and the max-over-ranks of the timings.  For N > 1 the line separates the step
+into its parts: `compute_only` (the blocks' kernels, no exchange), `exchange_only` (the
+allgatherv alone) and the step itself (both, overlapped).
 
 Default workload = the north-star target named in BASELINE.json / SURVEY.md §8(d):
 S32-band, 2^22 rows, exactly 32 nnz/row inside a +-4096 band, fp32 values, 32-bit
@@ -23,11 +28,14 @@ offsets, seed 1 (1 124.1 MB of compulsory traffic, far beyond the 256 MiB Infini
 Cache).  The other configs are parity-test cases (tests/test_gpu_parity.py); they can
 be timed with --workload.
 
-One JSON line on stdout (rank 0).  Extra objects:
+One JSON line on stdout (rank 0) — also when the run fails: a rank that dies, an RCCL
+or gloo call that does not return and a wall-clock limit all end in ONE line with an
+"error" field and a non-zero exit code, never in a hang.  Extra objects:
   roofline      achieved = ALGORITHMIC bytes of one SpMV / mean device time of one
                 execute = (HIP events recorded on the launch stream around the K timed
-                executes) / K; min / median from a second pass with events around every
-                execute; peak = 8000 GB/s (HBM3E spec, MI355X_MICROARCH.md);
+                executes) / K — for N > 1: this GPU's bytes / its compute-only time;
+                min / median from a second pass with events around every execute;
+                peak = 8000 GB/s (HBM3E spec, MI355X_MICROARCH.md);
                 traffic = HBM bytes per launch from rocprofv3 PMC passes (read from
                 profiles/, null if that file is absent)
   cpu_baseline  the reference's serial CPU SpMV (cpu_navie.hpp:5-17) timed on this
@@ -36,9 +44,11 @@ One JSON line on stdout (rank 0).  Extra objects:
                 else "port" = oracle/spmv_oracle.cpp.  Reported, not the target.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -56,6 +66,10 @@ try:
 except Exception:
     BASELINE_METRIC = "GFLOP/s (2*nnz/t) and achieved HBM GB/s, CSR SpMV fp32, 1/2/4/8 MI355X"
 KINDS = ("vector", "merge", "light")
+WORKLOADS = ["s32-band", "s32-rand", "c2-cant", "c3-webgoogle", "c4-nlpkkt", "c5-rmat24"]
+# wall-clock limit of a whole run and of one control-plane collective (a dead peer must not park the others)
+LIMIT_S = float(os.environ.get("MI355_BENCH_LIMIT_S", "900"))
+COLLECTIVE_S = float(os.environ.get("MI355_BENCH_COLLECTIVE_S", "180"))
 
 
 def parse():
@@ -63,8 +77,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="s32-band",
-                    choices=["s32-band", "s32-rand", "c2-cant", "c3-webgoogle", "c4-nlpkkt", "c5-rmat24"])
+    ap.add_argument("--workload", default="s32-band", choices=WORKLOADS)
+    ap.add_argument("--mtx", default=None, metavar="PATH",
+                    help="a Matrix Market coordinate file instead of a synthetic workload, read by the product loader "
+                         "(host/load.hpp through include/mi355_load.h: the reference's LoadCoo + ToCsr, main.cu:32-39)")
+    ap.add_argument("--dtype", choices=("f32", "f64"), default="f32", help="value type of --mtx")
+    ap.add_argument("--offset", choices=("32", "64"), default="32", help="offset width of --mtx")
     ap.add_argument("--kind", default="auto", choices=("auto",) + KINDS)
     ap.add_argument("--rows-log2", type=int, default=22, help="rows per GPU of the s32 workloads (2^k)")
     ap.add_argument("--band-half-width", type=int, default=4096,
@@ -82,13 +100,25 @@ def parse():
     ap.add_argument("--all-kinds", action="store_true", help="time every kind for K steps (extra field)")
     ap.add_argument("--sub-blocks", type=int, default=0,
                     help="row blocks per GPU in the multi-GPU path (0 = 4 when N > 1, else 1)")
+    ap.add_argument("--exchange", default="auto", choices=("auto", "bcast", "sendrecv", "allgather"),
+                    help="how the y slices travel when N > 1 (auto = the library's timed pick at create)")
     return ap.parse_args()
 
 
-def spawn_ranks(n):
+def error_line(msg, world, args=None):
+    """The JSON line of a failed run: same keys as a good one where they are known, value null, an "error"."""
+    return json.dumps({"metric": BASELINE_METRIC, "value": None, "unit": "GFLOP/s", "n_gpus": world,
+                       "steps": getattr(args, "steps", None), "warmup": getattr(args, "warmup", None),
+                       "higher_is_better": True, "vs_baseline": None, "data": "synthetic", "error": msg})
+
+
+def spawn_ranks(n, args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N rank processes here (fresh
-    children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; this parent never initialises a GPU),
-    pass rank 0's JSON line through and exit with the worst exit code."""
+    children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; this parent never initialises a GPU), pass rank 0's
+    JSON line through and exit with the worst exit code.  The children are WATCHED: the first one that exits
+    non-zero, or the wall-clock limit, ends the others (SIGTERM, then SIGKILL), and the parent prints one JSON line
+    with an "error" field — a rank that died in hipMalloc or ncclCommInitRank must not leave rank 0 waiting in a
+    barrier for the driver's time limit."""
     import socket
     import subprocess
     with socket.socket() as sk:
@@ -100,20 +130,79 @@ def spawn_ranks(n):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    t_end = time.monotonic() + LIMIT_S + 30          # (the ranks' own watchdogs fire first)
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = "rank %d exited with code %d" % bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > t_end:
+            failed = "wall-clock limit of %.0f s reached" % (LIMIT_S + 30)
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 5
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+    lines = [l for l in out.splitlines() if l.strip().startswith("{")]
+    if failed and not lines:
+        lines = [error_line("bench.py --gpus %d: %s; the other ranks were stopped" % (n, failed), n, args)]
+    sys.stdout.write("\n".join(lines) + ("\n" if lines else ""))
     sys.stdout.flush()
-    sys.exit(max(abs(c) for c in codes))
+    codes = [p.returncode for p in procs]
+    sys.exit(1 if failed else max(abs(c or 0) for c in codes))
+
+
+class Watchdog(threading.Thread):
+    """Every rank watches its own clock: past the limit (a collective that never returns, a peer that died without
+    the launcher noticing) rank 0 prints the error line and the process ends — os._exit works from a thread even while
+    the main thread sits in a C call.  `phase` names where the run was."""
+
+    def __init__(self, rank, world, args, json_fd):
+        super().__init__(daemon=True)
+        self.rank, self.world, self.args, self.json_fd = rank, world, args, json_fd
+        self.phase, self.done = "start", False
+        self.deadline = time.monotonic() + LIMIT_S
+
+    def run(self):
+        while not self.done:
+            if time.monotonic() > self.deadline:
+                msg = "bench.py rank %d/%d: no progress within %.0f s (last phase: %s)" % (self.rank, self.world, LIMIT_S, self.phase)
+                sys.stderr.write(msg + "\n")
+                if self.rank == 0:
+                    os.write(self.json_fd, (error_line(msg, self.world, self.args) + "\n").encode())
+                os._exit(3)
+            time.sleep(0.5)
+
+
+def load_matrix(sp, args, dev):
+    if args.mtx:
+        m = sp.load.load_mtx(args.mtx, torch.int64 if args.offset == "64" else torch.int32,
+                             torch.float64 if args.dtype == "f64" else torch.float32, dev)
+        if m.n_rows <= 0 or m.nnz <= 0:
+            raise SystemExit("bench.py: %s holds no rows / no nonzeros" % args.mtx)
+        return m
+    return sp.synth.workload(args.workload, dev)
 
 
 def build_local(sp, args, rank, world, dev, sub_blocks):
     """This rank's row block as a 16-byte-aligned view (spmv-samples_amd/dist.py block_view) + what
     mi355_spmv_dist_create_rank needs: the global cut lists of all world * sub_blocks blocks and, when ONE
-    matrix is cut (c5), the whole matrix's plan shape so that the blocks sum every row as one GPU would.
-    Returns (local Csr whose Ap[0] is the block's phase, cuts dict)."""
+    matrix is cut (every workload but the s32 ones), the whole matrix's plan shape so that the blocks sum every row
+    as one GPU would.  Returns (local Csr whose Ap[0] is the block's phase, cuts dict)."""
     parts = world * sub_blocks
-    if args.workload in ("s32-band", "s32-rand"):
+    if not args.mtx and args.workload in ("s32-band", "s32-rand"):
         # weak scaling: every rank generates its own 2^k rows of a banded matrix with world * 2^k rows; the
         # blocks are statistically alike, every rank can write down everybody's cuts (32 nonzeros per row)
         n = 1 << args.rows_log2
@@ -125,7 +214,7 @@ def build_local(sp, args, rank, world, dev, sub_blocks):
         sub = [(n * s // sub_blocks) & ~3 for s in range(sub_blocks)]
         rows = [r * n + o for r in range(world) for o in sub] + [world * n]
         return m, {"rows": rows, "chunks": None, "nnz": [32 * r for r in rows], "shape": None, "kind_shape": {}}
-    full = sp.synth.workload(args.workload, dev)
+    full = load_matrix(sp, args, dev)
     if world == 1 and sub_blocks == 1:
         return full, {"rows": [0, full.n_rows], "chunks": None, "nnz": [0, full.nnz], "shape": None, "kind_shape": {}}
     # strong scaling: ONE matrix, cut on the chunk boundaries of its own one-GPU plan (per kind)
@@ -137,17 +226,31 @@ def build_local(sp, args, rank, world, dev, sub_blocks):
     return full, {"rows": None, "chunks": None, "nnz": None, "shape": None, "kind_shape": kind_shape}
 
 
+class _NoPlan:
+    """A rank that owns no row (strong scaling of a tiny matrix): nothing to launch, still part of every collective."""
+
+    def execute(self, *a, **k):
+        pass
+
+    def info(self):
+        return {"lanes_per_row": 0, "grid_blocks": 0, "n_kernels": 0, "window_elems": 0, "window_segments": 0,
+                "knobs": "", "main_kernel": "none (this rank owns no rows)"}
+
+    def destroy(self):
+        pass
+
+
 class Runner:
     """One kind on this rank: a plain plan (single GPU, one block) or the library's multi-GPU object."""
 
-    def __init__(self, sp, kind, m, cuts, rank, world, sub_blocks, unique_id, flags, use_dist):
-        self.kind, self.m, self.use_dist = kind, m, use_dist
-        self.blocks, self.exchange = None, "none (single GPU)"
+    def __init__(self, sp, kind, m, cuts, rank, world, sub_blocks, unique_id, flags, use_dist, exchange="auto"):
+        self.kind, self.m, self.use_dist, self.sp = kind, m, use_dist, sp
+        self.blocks, self.exchange, self.dist_info = None, "none (single GPU)", None
         if not use_dist:
             self.plan = sp.Plan(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype, flags)
             self.Ax, self.n_rows_global, self.n_rows_local, self.nnz_local = m.Ax, m.n_rows, m.n_rows, m.nnz
             return
-        if kind in cuts["kind_shape"]:       # one matrix cut into blocks (c5): this rank keeps its view only
+        if kind in cuts["kind_shape"]:       # one matrix cut into blocks: this rank keeps its view only
             shape, rows, chunks, nnzs = cuts["kind_shape"][kind]
             first = rank * sub_blocks
             r0, r1 = rows[first], rows[first + sub_blocks]
@@ -160,14 +263,14 @@ class Runner:
         self.Ax = Ax_l
         self.n_rows_global, self.n_rows_local = rows[-1], r1 - r0
         self.nnz_local = nnzs[(rank + 1) * sub_blocks] - nnzs[rank * sub_blocks]
-        self.exchange = "mi355_spmv_dist_* (grouped in-place ncclBroadcast per sub-block on a communication stream)"
-        self.blocks = None
         err = ""
         try:
             self.plan = sp.DistPlan.rank(kind, rank, world, unique_id, sub_blocks, rows, chunks, nnzs, shape, m.n_cols,
-                                         r1 - r0, int(Ap_l[-1].item()), Ap_l, Aj_l, m.Ax.dtype, flags)
+                                         r1 - r0, int(Ap_l[-1].item()) if r1 > r0 else 0, Ap_l, Aj_l, m.Ax.dtype, flags)
+            if exchange != "auto" and world > 1:
+                self.plan.set_exchange(exchange)
             ok = 1
-        except RuntimeError as e:              # (never seen: the N > 1 leg cannot be rehearsed on the one-GPU test pool)
+        except RuntimeError as e:
             self.plan, ok, err = None, 0, str(e)
         if os.environ.get("MI355_BENCH_FORCE_FALLBACK"):     # (rehearsal of the safety net on one GPU)
             ok, err = 0, "forced by MI355_BENCH_FORCE_FALLBACK"
@@ -178,6 +281,13 @@ class Runner:
         self._fb = (sp, rank, world, sub_blocks, rows, chunks, nnzs, shape, r0, Ap_l, Aj_l, Ax_l, flags)
         if not ok:
             self.fall_back(err)
+        else:
+            self.dist_info = self.plan.dist_info()
+            t = self.dist_info["trial_us"]
+            self.exchange = ("mi355_spmv_dist_* %s per sub-block on a communication stream" % self.dist_info["exchange_name"]) + (
+                " (the library's timed pick: bcast %.0f / sendrecv %.0f / allgather %.0f us per exchange of all sub-blocks)"
+                % (t["bcast"], t["sendrecv"], t["allgather"]) if self.dist_info["auto_picked"] else
+                (" (forced)" if world > 1 else " (one GPU: no communicator)"))
 
     def fall_back(self, err):
         """Safety net so that a scaling run still measures something: the same row blocks through the C ABI's
@@ -188,26 +298,28 @@ class Runner:
             self.plan.destroy()
         sys.stderr.write("bench.py: the library's multi-GPU object failed (%s); exchanging y through torch.distributed\n" % err)
         self.exchange = "FALLBACK torch.distributed over RCCL (the library's own communicator failed: %s)" % (err or "on another rank")
-        self.pg = dist.new_group(backend="nccl")
+        self.dist_info = None
+        self.pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=COLLECTIVE_S))
         self.rank_cuts = [rows[r * sub_blocks] for r in range(world)] + [rows[-1]]
         self.blocks = []
         for b in range(rank * sub_blocks, (rank + 1) * sub_blocks):
-            a, j, v, _ = sp.dist.block_view(Ap_l, Aj_l, Ax_l, rows[b] - r0, rows[b + 1] - r0)
             if rows[b + 1] == rows[b]:
                 continue
+            a, j, v, _ = sp.dist.block_view(Ap_l, Aj_l, Ax_l, rows[b] - r0, rows[b + 1] - r0)
             cb = chunks[b] if chunks is not None else 0
             nc = (chunks[b + 1] - chunks[b]) if chunks is not None else 0
             pl = sp.Plan.block(kind, shape, rows[b], cb, nc, nnzs[b], rows[b + 1] - rows[b], m.n_cols,
                                int(a[-1].item()), a, j, m.Ax.dtype, flags)
             self.blocks.append((pl, v, rows[b], rows[b + 1]))
-        self.plan = self.blocks[0][0]
-        self.sp, self.rank = sp, rank
+        # (a rank whose blocks are all empty keeps an empty list: it still enters every collective below)
+        self.plan = self.blocks[0][0] if self.blocks else _NoPlan()
+        self.rank = rank
 
     def check_exchange(self, x, y):
-        """N > 1 only (cannot be rehearsed on the one-GPU test pool, so the run checks itself): one step on a y
-        poisoned with NaN; afterwards every rank must hold, for every rank's rows, the very bits their owner
-        holds (a checksum of the raw words per slice, compared over the gloo control plane), and no NaN.
-        A failed step or a mismatch anywhere sends every rank to the torch.distributed fallback, once."""
+        """N > 1 (and the N = 1 rehearsal): one step on a y poisoned with NaN; afterwards every rank must hold, for
+        every rank's rows, the very bits their owner holds (a checksum of the raw words per slice, compared over the
+        gloo control plane), and no NaN.  A failed step or a mismatch anywhere sends every rank to the
+        torch.distributed fallback, once."""
         sp, rank, world, sub_blocks, rows = self._fb[:5]
         cuts = [rows[r * sub_blocks] for r in range(world)] + [rows[-1]]
         for attempt in range(2):
@@ -235,14 +347,20 @@ class Runner:
             self.fall_back(err)
         return "FAILED"
 
-    def execute(self, x, y):
+    def execute(self, x, y, leg="step"):
+        """leg: "step" (kernels + exchange), "compute" (kernels only), "exchange" (the allgatherv only)."""
         if self.blocks is None:
-            self.plan.execute(self.Ax, x, y)
+            if not self.use_dist:
+                self.plan.execute(self.Ax, x, y)
+            else:
+                self.plan.execute(self.Ax, x, y, flags={"step": 0, "compute": 1, "exchange": 2}[leg])
             return
-        for pl, v, b0, b1 in self.blocks:
-            pl.execute(v, x, y[b0:b1])
-        lo, hi = self.rank_cuts[self.rank], self.rank_cuts[self.rank + 1]
-        self.sp.dist.allgatherv(y[lo:hi], y, self.rank_cuts, group=self.pg)
+        if leg != "exchange":
+            for pl, v, b0, b1 in self.blocks:
+                pl.execute(v, x, y[b0:b1])
+        if leg != "compute":
+            lo, hi = self.rank_cuts[self.rank], self.rank_cuts[self.rank + 1]
+            self.sp.dist.allgatherv(y[lo:hi], y, self.rank_cuts, group=self.pg)
 
     def info(self):
         return self.plan.info()        # (multi-GPU object: its first block's launch shape)
@@ -256,16 +374,18 @@ class Runner:
 
 
 _FLUSH = {"buf": None}
+_STATE = {}       # json_fd / rank / world / args once stdout has been redirected (for the error line of a crashed run)
 
 
-def time_steps(run, x, y, use_dist, steps, per_step=False):
+def time_steps(run, x, y, use_dist, steps, per_step=False, leg="step"):
     """K steps; returns (wall seconds between the two syncs, list of device ms).
     per_step=False (the timed region): ONE pair of HIP events around the K executes, on the stream they are
     launched on — the list holds their mean, K times.  per_step=True (a separate, instrumented pass; always in
     --cold mode): a pair around EVERY execute, for the minimum / median — each pair costs the stream ~6 us of wall
     per step (184.1 vs 178.8 us), which is why the timed region does not carry them.
     A step of the multi-GPU path is complete when this GPU holds the WHOLE y (the library makes the caller's stream
-    wait for its communication stream), so the events bracket SpMV + exchange there."""
+    wait for its communication stream), so the events bracket SpMV + exchange there; leg = "compute" / "exchange"
+    runs one half only (mi355_spmv_dist_execute_ex)."""
     per_step = per_step or _FLUSH["buf"] is not None
     n_ev = steps if per_step else 1
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
@@ -280,7 +400,7 @@ def time_steps(run, x, y, use_dist, steps, per_step=False):
             _FLUSH["buf"].fill_(float(i))      # cold mode: evict the matrix from L2 / Infinity Cache
         if per_step:
             evs[i][0].record()
-        run.execute(x, y)
+        run.execute(x, y, leg)
         if per_step:
             evs[i][1].record()
     if not per_step:
@@ -292,6 +412,22 @@ def time_steps(run, x, y, use_dist, steps, per_step=False):
     if per_step:
         return wall, [a.elapsed_time(b) for a, b in evs]
     return wall, [evs[0][0].elapsed_time(evs[0][1]) / steps] * steps
+
+
+def pick_kind(runs, x, y, use_dist, warmup):
+    """--kind auto, outside the timed region.  Every kind is first warmed for max(W, 70) executes (an HBM-bound kernel
+    needs ~60-70 from a fresh plan to reach its steady time, profiles/r02_warmup_curve.txt); then the kinds are probed
+    INTERLEAVED — A B C A B C ..., 7 rounds of 10 executes each — so that no kind owns the clock / cache state the
+    previous one left, and the MEDIAN of a kind's rounds decides (max over ranks when N > 1)."""
+    for r in runs.values():
+        time_steps(r, x, y, use_dist, max(warmup, 70))
+    samples = {k: [] for k in runs}
+    for _ in range(7):
+        for k, r in runs.items():
+            _, ms = time_steps(r, x, y, use_dist, 10)
+            samples[k].append(float(ms[0]))
+    med = {k: float(np.median(v)) for k, v in samples.items()}
+    return med
 
 
 def one_shot_ms(sp, kind, m, x, y, reps=5, first=False):
@@ -370,7 +506,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # by torch.distributed.run or by spawn_ranks
     if not launched and args.gpus > 1:
-        spawn_ranks(args.gpus)                                          # (does not return)
+        spawn_ranks(args.gpus, args)                                    # (does not return)
     if launched:
         args.gpus = world
     # stdout carries exactly ONE line, the JSON: gloo ("[Gloo] Rank 0 is connected ...") and RCCL (its version banner)
@@ -378,6 +514,9 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    _STATE.update(json_fd=json_fd, rank=rank, world=world, args=args)
+    dog = Watchdog(rank, world, args, json_fd)
+    dog.start()
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -388,8 +527,10 @@ def main():
     sp = graft.load_package()
     unique_id = None
     if use_dist:
+        dog.phase = "gloo rendezvous"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # (every control-plane collective inherits this limit: a rank whose peer died gets an exception, not a wait)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=COLLECTIVE_S))
         if world > 1:
             box = [sp.DistPlan.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
@@ -397,64 +538,91 @@ def main():
 
     if args.cold:
         _FLUSH["buf"] = torch.empty(512 << 18, dtype=torch.float32, device=dev)   # 512 MiB
+    dog.phase = "building the matrix"
     m, cuts = build_local(sp, args, rank, world, dev, sub_blocks) if use_dist else build_local(sp, args, 0, 1, dev, 1)
     x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, dev)  # same seed on every rank: replicated x
     flags = sp.capi.PLAN_REUSE_STRUCTURE if args.reuse_structure else 0
     kinds = KINDS if args.kind == "auto" or args.all_kinds else (args.kind,)
-    if True:
-        # (a fresh 128-byte id per communicator: one per kind when several kinds are timed)
-        runs = {}
-        for k in kinds:
-            uid = unique_id
-            if use_dist and world > 1 and runs:
-                box = [sp.DistPlan.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                uid = box[0]
-            runs[k] = Runner(sp, k, m, cuts, rank, world, sub_blocks, uid, flags, use_dist)
-        n_rows_global = next(iter(runs.values())).n_rows_global
-        y = torch.empty(n_rows_global, dtype=m.Ax.dtype, device=dev)
-        checks = {k: r.check_exchange(x, y) for k, r in runs.items()} if use_dist and (world > 1 or os.environ.get("MI355_BENCH_CHECK_EXCHANGE")) else {}   # (the knob: N = 1 rehearsal)
+    # (a fresh 128-byte id per communicator: one per kind when several kinds are timed)
+    runs = {}
+    for k in kinds:
+        dog.phase = "creating the %s plan / communicator (exchange trial inside)" % k
+        uid = unique_id
+        if use_dist and world > 1 and runs:
+            box = [sp.DistPlan.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        runs[k] = Runner(sp, k, m, cuts, rank, world, sub_blocks, uid, flags, use_dist, args.exchange)
+    n_rows_global = next(iter(runs.values())).n_rows_global
+    y = torch.empty(n_rows_global, dtype=m.Ax.dtype, device=dev)
+    dog.phase = "exchange self-check"
+    checks = {k: r.check_exchange(x, y) for k, r in runs.items()} if use_dist and (world > 1 or os.environ.get("MI355_BENCH_CHECK_EXCHANGE")) else {}   # (the knob: N = 1 rehearsal)
 
-        # warm-up; with --kind auto the warm-up also picks the kind (outside the timed region)
-        probe = {}
-        for k, r in runs.items():
-            time_steps(r, x, y, use_dist, max(args.warmup, 1))   # warm-up proper
-        for k, r in runs.items():
-            _, ms = time_steps(r, x, y, use_dist, max(args.warmup, 30))
-            probe[k] = float(np.mean(ms))
+    # warm-up; with --kind auto the warm-up also picks the kind (outside the timed region)
+    dog.phase = "warm-up / kind probe"
     kind = args.kind
     if kind == "auto":
+        probe = pick_kind(runs, x, y, use_dist, args.warmup)
         best = torch.tensor([probe[k] for k in KINDS], dtype=torch.float64)
         if use_dist:
             dist.all_reduce(best, op=dist.ReduceOp.MAX)
         kind = KINDS[int(torch.argmin(best).item())]
+    else:
+        probe = {}
+        for k, r in runs.items():
+            time_steps(r, x, y, use_dist, max(args.warmup, 70))
     run = runs[kind]
+    time_steps(run, x, y, use_dist, max(args.warmup, 1))                     # the W warm-up steps proper, on the kind that is timed
 
+    dog.phase = "timed region"
     wall, dev_list = time_steps(run, x, y, use_dist, args.steps)            # THE timed region
-    dev_ms = float(np.mean(dev_list))
-    _, step_list = time_steps(run, x, y, use_dist, args.steps, per_step=True)   # instrumented pass: spread of single executes
+    step_dev_ms = float(np.mean(dev_list))
+    multi = use_dist and world > 1
+    legs = {}
+    if multi or (use_dist and os.environ.get("MI355_BENCH_LEGS")):          # (the knob: N = 1 rehearsal of the two legs)
+        dog.phase = "compute-only / exchange-only legs"
+        for leg in ("compute", "exchange"):
+            time_steps(run, x, y, use_dist, 5, leg=leg)
+            w, ms = time_steps(run, x, y, use_dist, args.steps, leg=leg)
+            t = torch.tensor([float(np.mean(ms)), w / args.steps * 1e3], dtype=torch.float64)
+            tmax, tmin = t.clone(), t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+            legs[leg] = {"ms": float(t[0].item()), "ms_max_over_gpus": float(tmax[0].item()),
+                         "ms_min_over_gpus": float(tmin[0].item()), "wall_ms_per_step": float(tmax[1].item())}
+        run.execute(x, y)                                                    # (leave a whole y behind)
+    dev_ms = legs["compute"]["ms"] if "compute" in legs else step_dev_ms     # this GPU's kernels
+    dog.phase = "instrumented pass"
+    _, step_list = time_steps(run, x, y, use_dist, args.steps, per_step=True, leg="compute" if legs else "step")   # spread of single executes
     tmax = torch.tensor([wall], dtype=torch.float64)
     nnz_all = torch.tensor([float(run.nnz_local)], dtype=torch.float64)
+    v, o = m.Ax.element_size(), m.Ap.element_size()
+    bytes_alg = run.nnz_local * (v + 4) + (run.n_rows_local + 1) * o + run.n_rows_local * v + m.n_cols * v
+    frac = torch.tensor([bytes_alg / (max(dev_ms, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBPS], dtype=torch.float64)
+    frac_min, frac_max = frac.clone(), frac.clone()
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nnz_all, op=dist.ReduceOp.SUM)
+        dist.all_reduce(frac_min, op=dist.ReduceOp.MIN)
+        dist.all_reduce(frac_max, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
     total_nnz = float(nnz_all.item())
 
-    v, o = m.Ax.element_size(), m.Ap.element_size()
-    bytes_alg = run.nnz_local * (v + 4) + (run.n_rows_local + 1) * o + run.n_rows_local * v + m.n_cols * v
     others = {}
     if args.all_kinds:
+        dog.phase = "--all-kinds"
         for k, r in runs.items():
             _, ms = time_steps(r, x, y, use_dist, args.steps)
             ms = float(np.mean(ms))
             others[k] = {"kernel_ms": ms, "gflops": 2.0 * r.nnz_local / ms / 1e6, "gbps": bytes_alg / ms / 1e6}
 
     if rank == 0:
+        dog.phase = "report"
         strong = bool(cuts["kind_shape"])
         info = run.info()
         achieved = bytes_alg / (dev_ms * 1e-3) / 1e9
         traffic, traffic_source = read_traffic(info["main_kernel"], bytes_alg)
+        step_ms = wall / args.steps * 1e3
         out = {
             # BASELINE.json's metric, verbatim; `value` is its GFLOP/s part, the achieved HBM GB/s part
             # is `achieved_hbm_gbps` / `roofline.achieved`
@@ -462,16 +630,17 @@ def main():
             "value": 2.0 * total_nnz * args.steps / wall / 1e9,
             "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
+            "ms_per_step": step_ms,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32" if m.Ax.dtype == torch.float32 else "f64",
-            "data": "synthetic",
-            "config": {"workload": ("%s: %d rows, %d nnz cut into %d nnz-balanced row blocks (%d per GPU), %s offsets, seeded"
+            "data": "file" if args.mtx else "synthetic",
+            "config": {"workload": ("%s: %d rows, %d nnz cut into %d nnz-balanced row blocks (%d per GPU), %s offsets%s"
                                     % (m.name, m.n_rows, m.nnz, world * sub_blocks, sub_blocks,
-                                       "i32" if m.Ap.dtype == torch.int32 else "i64")) if strong else
-                                   ("%s: %d rows/GPU x %d GPU, %d nnz/GPU, %s offsets, seeded"
+                                       "i32" if m.Ap.dtype == torch.int32 else "i64", "" if args.mtx else ", seeded")) if strong else
+                                   ("%s: %d rows/GPU x %d GPU, %d nnz/GPU, %s offsets%s"
                                     % (m.name, run.n_rows_local, world, run.nnz_local,
-                                       "i32" if m.Ap.dtype == torch.int32 else "i64")),
+                                       "i32" if m.Ap.dtype == torch.int32 else "i64",
+                                       ", Matrix Market file through the product loader" if args.mtx else ", seeded")),
                        "kind": kind, "lanes_per_row": info["lanes_per_row"], "grid_blocks": info["grid_blocks"],
                        "kernels_per_step": info["n_kernels"], "x_window_elems": info["window_elems"],
                        "x_window_segments": info["window_segments"], "reuse_structure": bool(args.reuse_structure),
@@ -479,9 +648,9 @@ def main():
                        "parallelism": ("%d GPU x %d row blocks, x replicated, allgatherv(y): %s" % (world, sub_blocks, run.exchange))
                                       if use_dist else "single GPU"},
             "achieved_hbm_gbps": achieved,
-            # this GPU's step by HIP events: the SpMV alone on one GPU; SpMV + exchange when N > 1
+            # this GPU's kernels by HIP events (N > 1: the compute-only leg), the step with its exchange beside it
             "compute_only": {"ms": dev_ms, "gflops_per_gpu": 2.0 * run.nnz_local / dev_ms / 1e6,
-                             "step_ms_incl_exchange": wall / args.steps * 1e3},
+                             "step_ms_incl_exchange": step_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": info["main_kernel"], "kernel_ms": dev_ms,
@@ -492,9 +661,31 @@ def main():
                                    "launch stream; min / median / mean_instrumented = a second pass of K executes with a "
                                    "pair around each" if _FLUSH["buf"] is None else
                                    "HIP events around every execute of the timed region (cold mode)") +
-                                  (" (SpMV + exchange of this GPU)" if use_dist and world > 1 else "")},
+                                  (" (N > 1: the compute-only leg of this GPU, its own bytes; the step with the exchange is "
+                                   "ms_per_step)" if legs else "")},
             "warmup_probe_ms": probe,
         }
+        if probe:
+            out["kind_pick"] = "every kind warmed for %d executes, then 7 interleaved rounds of 10; median per kind%s" % (
+                max(args.warmup, 70), ", max over ranks" if multi else "")
+        if legs:
+            ex = legs["exchange"]
+            out["compute_only"].update({"ms_max_over_gpus": legs["compute"]["ms_max_over_gpus"],
+                                        "ms_min_over_gpus": legs["compute"]["ms_min_over_gpus"],
+                                        "wall_ms_per_step": legs["compute"]["wall_ms_per_step"]})
+            out["exchange_only"] = {"ms": ex["ms"], "ms_max_over_gpus": ex["ms_max_over_gpus"],
+                                    "wall_ms_per_step": ex["wall_ms_per_step"],
+                                    "y_bytes_received_per_gpu": int((n_rows_global - run.n_rows_local) * v),
+                                    "gbps_in_per_gpu": (n_rows_global - run.n_rows_local) * v / max(ex["ms_max_over_gpus"], 1e-9) / 1e6}
+            out["exchange_ms"] = ex["ms_max_over_gpus"]
+            out["overlap"] = {"step_ms": step_ms,
+                              "compute_plus_exchange_ms": legs["compute"]["ms_max_over_gpus"] + ex["ms_max_over_gpus"],
+                              "hidden_ms": legs["compute"]["ms_max_over_gpus"] + ex["ms_max_over_gpus"] - step_ms}
+            out["roofline"]["frac_min_over_gpus"] = float(frac_min.item())
+            out["roofline"]["frac_max_over_gpus"] = float(frac_max.item())
+            out["gflops_compute_only_all_gpus"] = 2.0 * total_nnz / max(legs["compute"]["ms_max_over_gpus"], 1e-9) / 1e6
+        if run.dist_info:
+            out["exchange"] = run.dist_info
         if checks:
             out["exchange_check"] = checks[kind]
         if others:
@@ -504,15 +695,29 @@ def main():
             out["one_shot_first_ms"] = one_shot_ms(sp, kind, m, x, y, first=True)   # a first call: plan created
             sp.capi.cache_release()
         if world == 1 and not args.no_cpu_baseline:
+            dog.phase = "cpu baseline"
+            dog.deadline += args.cpu_seconds + 120
             out["cpu_baseline"] = cpu_baseline(m, x, args.cpu_seconds)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    dog.phase = "teardown"
     for r in runs.values():
         r.destroy()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    dog.done = True
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:      # noqa: BLE001 - a run that dies still ends in ONE JSON line (rank 0) and a non-zero code
+        import traceback
+        traceback.print_exc()
+        if _STATE.get("rank", 0) == 0:
+            line = error_line("bench.py: %s: %s" % (type(e).__name__, str(e)[:400]), _STATE.get("world", 1), _STATE.get("args"))
+            os.write(_STATE.get("json_fd", 1), (line + "\n").encode())
+        os._exit(1)                 # (not sys.exit: a rank stuck in a collective's destructor must not outlive the error)

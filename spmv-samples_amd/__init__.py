@@ -14,6 +14,7 @@ Contents (only what the hot path needs):
     capi.py    ctypes binding used by tests and bench.py
     synth.py   seeded synthetic CSR matrices (stand-ins for the BASELINE configs)
     dist.py    row-block sharding + allgatherv(y) for one process per GPU
+    load.py    ctypes binding of the Matrix Market loader (include/mi355_load.h, host/load.hpp)
 """
-from . import capi, dist, synth  # noqa: F401
+from . import capi, dist, load, synth  # noqa: F401
 from .capi import DistPlan, Plan, PlanShape, spmv, spmv_genl, spmv_mixed  # noqa: F401

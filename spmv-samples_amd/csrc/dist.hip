@@ -667,7 +667,7 @@ int mi355_spmv_dist_create_local(mi355_spmv_dist** out, int kind, int off_type, 
     d->home = -1;
     const bool shared_ok = knobs().dist_shared_device != 0;    // (an emulated RCCL: several "GPUs" on one device)
     for (int i = 0; i < n_devices; ++i) {
-        d->devs[i].device = devices ? devices[i] : i;
+        d->devs[i].device = devices ? devices[i] : (shared_ok ? home_device : i);   // (emulated RCCL: every "GPU" is the current device)
         if (d->devs[i].device == home_device && d->home < 0) d->home = i;
         for (int j = 0; j < i && !shared_ok; ++j)
             if (d->devs[j].device == d->devs[i].device) {

@@ -41,6 +41,7 @@
 #include <exception>
 #include <iostream>
 #include <limits>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -211,6 +212,19 @@ inline size_t count_tokens(const char* b, const char* e, const char* file_begin)
     return n;
 }
 
+// The reference prints its message and exits the process on an unreadable file, a bad banner, an array file, a bad
+// size line or a complex field (load.hpp:278-300, :357-360): the harness keeps that.  A library cannot: built with
+// MI355_LOAD_NO_EXIT (host/load_capi.cpp) the same sites throw fatal_t instead.
+struct fatal_t : std::runtime_error { using std::runtime_error::runtime_error; };
+[[noreturn]] inline void fatal(const std::string& message) {
+#ifdef MI355_LOAD_NO_EXIT
+    throw fatal_t(message);
+#else
+    std::cerr << message << std::endl;
+    std::exit(1);
+#endif
+}
+
 inline unsigned parse_threads() {
     if (const char* v = std::getenv("MI355_LOAD_THREADS")) {
         const int n = std::atoi(v);
@@ -226,18 +240,12 @@ template <typename index_t, typename offset_t, typename value_t>
 coo_t<index_t, offset_t, value_t> LoadCoo(std::string filename) {
     using namespace mm_detail;
     Mapped f;
-    if (!f.open(filename)) {
-        std::cerr << "File could not be opened: " << filename << std::endl;
-        std::exit(1);
-    }
+    if (!f.open(filename)) fatal("File could not be opened: " + filename);
     const char* p = f.data;
     const char* const end = f.data + f.size;
 
     // ---- banner: five tokens, fields 2..5 case-insensitive
-    auto banner_fail = [] {
-        std::cerr << "Could not process Matrix Market banner" << std::endl;
-        std::exit(1);
-    };
+    auto banner_fail = [] { fatal("Could not process Matrix Market banner"); };
     std::string line;
     if (!get_line(p, end, line)) banner_fail();
     char t0[1025], t1[1025], t2[1025], t3[1025], t4[1025];
@@ -250,16 +258,10 @@ coo_t<index_t, offset_t, value_t> LoadCoo(std::string filename) {
     if (field != "real" && field != "complex" && field != "pattern" && field != "integer") banner_fail();
     if (symmetry != "general" && symmetry != "symmetric" && symmetry != "hermitian" && symmetry != "skew-symmetric")
         banner_fail();
-    if (format == "array") {
-        std::cerr << "File is not a sparse matrix" << std::endl;
-        std::exit(1);
-    }
+    if (format == "array") fatal("File is not a sparse matrix");
 
     // ---- size line: first line not starting with '%'; blank -> next three numbers of the stream
-    auto size_fail = [] {
-        std::cerr << "Could not read file info (M, N, NNZ)" << std::endl;
-        std::exit(1);
-    };
+    auto size_fail = [] { fatal("Could not read file info (M, N, NNZ)"); };
     size_t n_rows = 0, n_cols = 0, n_entries = 0;
     do {
         if (!get_line(p, end, line)) size_fail();
@@ -273,16 +275,14 @@ coo_t<index_t, offset_t, value_t> LoadCoo(std::string filename) {
     throw_if_exception(n_entries >= size_t(std::numeric_limits<offset_t>::max()), "edge_t overflow");
 
     const bool pattern = field == "pattern";
-    if (!pattern && field != "real" && field != "integer") {
-        std::cerr << "Unrecognized matrix market format type" << std::endl;
-        std::exit(1);
-    }
+    if (!pattern && field != "real" && field != "integer") fatal("Unrecognized matrix market format type");
     coo_t<index_t, offset_t, value_t> coo{static_cast<index_t>(n_rows), static_cast<index_t>(n_cols),
                                           static_cast<offset_t>(n_entries)};
 
     // ---- entries, in parallel.  Pass 1: token census per chunk.  Pass 2: each chunk parses the
     //      entries whose FIRST token starts inside it.
     const size_t tokens_per_entry = pattern ? 2 : 3;
+    const bool mirror = symmetry == "symmetric";
     const char* const body = p;
     const size_t body_size = size_t(end - body);
     unsigned n_thr = parse_threads();
@@ -329,6 +329,7 @@ coo_t<index_t, offset_t, value_t> LoadCoo(std::string filename) {
             // The reference does not look (load.hpp:329-343 there) and then indexes out of bounds in ToCsr and,
             // through x[column], on the device: a file that passes here behaves exactly as it does there.
             if (r > n_rows || cidx > n_cols) { status[c] = 3; return; }
+            if (mirror && (cidx > n_rows || r > n_cols)) { status[c] = 3; return; }   // (the expansion stores (c, r) too)
             coo.row_indices[entry] = index_t(r) - 1;
             coo.column_indices[entry] = index_t(cidx) - 1;
             coo.nonzero_values[entry] = pattern ? value_t(1.0) : value_t(w);

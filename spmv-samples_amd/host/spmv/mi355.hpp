@@ -99,13 +99,21 @@ void run_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const offs
 // the same 8 arguments — device arrays on the CURRENT device — and spread the rows over dist_gpus() GPUs of
 // the node through mi355_spmv_dist_* (LOCAL mode: this one host thread drives every GPU).  Unlike the
 // single-GPU kinds they keep their handle between calls (cutting the matrix and copying the blocks to the
-// other GPUs per call would dwarf the SpMV): the handle is rebuilt when the structure arrays or sizes
-// change, the values are re-scattered when the Ax pointer changes (a caller that rewrites Ax in place calls
-// dist_release()), x is re-replicated on EVERY call, as SpMV(kind, ...) hands over a fresh x each time.
+// other GPUs per call would dwarf the SpMV) — and the handle holds COPIES of the structure, so, to keep the
+// semantics of SpMV(kind, ...), which reads its arrays on every call:
+//   * the handle is rebuilt when the pointers or sizes change, AND when the fingerprint of Ap / Aj differs from
+//     the one taken at create (mi355_spmv_dist_structure_changed: one small kernel per call; a matrix rewritten
+//     in place, or another one at the same addresses).  MI355_DIST_TRUST_STRUCTURE=1 skips that check;
+//   * Ax is scattered to the other GPUs on EVERY call (values rewritten in place: an iterative solver);
+//     MI355_DIST_REUSE_VALUES=1 scatters only when the Ax pointer changes;
+//   * x is replicated on every call.
 inline int& dist_gpus() {
     static int n = [] { const char* e = std::getenv("MI355_NGPU"); const int v = e ? std::atoi(e) : 1; return v > 0 ? v : 1; }();
     return n;
 }
+inline bool env_flag(const char* name) { const char* e = std::getenv(name); return e && std::atoi(e) != 0; }
+inline bool& dist_trust_structure() { static bool v = env_flag("MI355_DIST_TRUST_STRUCTURE"); return v; }
+inline bool& dist_reuse_values() { static bool v = env_flag("MI355_DIST_REUSE_VALUES"); return v; }
 inline int& dist_sub_blocks() {
     static int n = [] { const char* e = std::getenv("MI355_SUB_BLOCKS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();
     return n;
@@ -140,9 +148,14 @@ void run_dist_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const
     const int gpus = dist_gpus();
     const int sub = dist_sub_blocks() > 0 ? dist_sub_blocks() : (gpus > 1 ? 4 : 1);
     DistCache& c = dist_cache();
-    const bool same = c.d && c.kind == kind && c.off_type == off_type && c.val_type == val_type && c.gpus == gpus &&
-                      c.sub == sub && c.n_rows == (long long)n_rows && c.n_cols == (long long)n_cols &&
-                      c.nnz == (long long)nnz && c.Ap == Ap && c.Aj == Aj;
+    bool same = c.d && c.kind == kind && c.off_type == off_type && c.val_type == val_type && c.gpus == gpus &&
+                c.sub == sub && c.n_rows == (long long)n_rows && c.n_cols == (long long)n_cols &&
+                c.nnz == (long long)nnz && c.Ap == Ap && c.Aj == Aj;
+    if (same && !dist_trust_structure()) {
+        int changed = 0;
+        MI355_CHECK(mi355_spmv_dist_structure_changed(c.d, Ap, reinterpret_cast<const int32_t*>(Aj), /*stream=*/nullptr, &changed));
+        same = !changed;
+    }
     if (!same) {
         dist_release();
         MI355_CHECK(mi355_spmv_dist_create_local(&c.d, kind, off_type, val_type, (int32_t)n_rows, (int32_t)n_cols,
@@ -151,7 +164,7 @@ void run_dist_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const
         c.kind = kind; c.off_type = off_type; c.val_type = val_type; c.gpus = gpus; c.sub = sub;
         c.n_rows = n_rows; c.n_cols = n_cols; c.nnz = nnz; c.Ap = Ap; c.Aj = Aj; c.Ax = nullptr;
     }
-    const void* ax = (gpus > 1 && c.Ax == Ax) ? nullptr : Ax;   // NULL = the other GPUs already hold these values
+    const void* ax = (gpus > 1 && dist_reuse_values() && c.Ax == Ax) ? nullptr : Ax;   // NULL = the other GPUs keep the values they hold
     Timer::kernel_start();
     MI355_CHECK(mi355_spmv_dist_execute(c.d, ax, x, y, /*stream=*/nullptr));
     MI355_CHECK(mi355_spmv_stream_synchronize(/*stream=*/nullptr));

@@ -209,8 +209,67 @@ static int run_integer() {
     return failures;
 }
 
+// The multi-GPU kinds keep a handle that holds COPIES of the structure; SpMV(kind, ...) reads its arrays on every call
+// (the reference has no state between calls).  So: a call, then the matrix rewritten IN PLACE — other row lengths and
+// columns, same sizes, same addresses — and the values and x as well, then a second call that must see all of it.
+//   boundary_test --dist-rewrite [gpus]      (gpus > 1: under the emulated RCCL, see tests/test_gpu_host.py)
+static int run_dist_rewrite(int gpus) {
+    using value_t = float;
+    const int n_rows = 6000, n_cols = 5000;
+    mi355_host::dist_gpus() = gpus;
+    mi355_host::dist_sub_blocks() = 3;
+    int failures = 0;
+    int* dAp; int* dAj; value_t *dAx, *dX, *dY;
+    std::vector<int> Ap(n_rows + 1), Aj;
+    std::vector<value_t> Ax, x(n_cols), y(n_rows);
+    const int nnz = 24 * n_rows;
+    HIP_OK(hipMalloc((void**)&dAp, (n_rows + 1) * sizeof(int)));
+    HIP_OK(hipMalloc((void**)&dAj, (size_t(nnz) + 4) * sizeof(int)));
+    HIP_OK(hipMalloc((void**)&dAx, (size_t(nnz) + 4) * sizeof(value_t)));
+    HIP_OK(hipMalloc((void**)&dX, n_cols * sizeof(value_t)));
+    HIP_OK(hipMalloc((void**)&dY, n_rows * sizeof(value_t)));
+    for (const char* label : {"hip_dist_vector", "hip_dist_merge", "hip_dist_light"}) {
+        for (int version = 0; version < 2; ++version) {
+            unsigned long long seed = 99 + 17 * version;
+            // version 0: 24 per row; version 1: 8 / 40 alternating (same nnz), other columns, other values, other x
+            Aj.clear(); Ax.clear();
+            Ap[0] = 0;
+            for (int r = 0; r < n_rows; ++r) {
+                const int len = version == 0 ? 24 : ((r & 1) ? 40 : 8);
+                for (int k = 0; k < len; ++k) {
+                    Aj.push_back(int(lcg(seed) % (unsigned)n_cols));
+                    Ax.push_back(value_t(double(lcg(seed) % 2001) / 1000.0 - 1.0));
+                }
+                Ap[r + 1] = int(Aj.size());
+            }
+            for (int c = 0; c < n_cols; ++c) x[c] = value_t(double(lcg(seed) % 2001) / 1000.0 - 1.0);
+            HIP_OK(hipMemcpy(dAp, Ap.data(), (n_rows + 1) * sizeof(int), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(dAj, Aj.data(), size_t(nnz) * sizeof(int), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(dAx, Ax.data(), size_t(nnz) * sizeof(value_t), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(dX, x.data(), n_cols * sizeof(value_t), hipMemcpyHostToDevice));
+            std::vector<value_t> poison(n_rows, std::numeric_limits<value_t>::quiet_NaN());
+            HIP_OK(hipMemcpy(dY, poison.data(), n_rows * sizeof(value_t), hipMemcpyHostToDevice));
+            SpMV<int, int, value_t, value_t, value_t>(label, n_rows, n_cols, nnz, dAp, dAj, dAx, dX, dY);
+            HIP_OK(hipMemcpy(y.data(), dY, n_rows * sizeof(value_t), hipMemcpyDeviceToHost));
+            int bad = 0;
+            for (int r = 0; r < n_rows; ++r) {
+                double s = 0, a = 0;
+                for (int k = Ap[r]; k < Ap[r + 1]; ++k) { const double p = double(Ax[k]) * double(x[Aj[k]]); s += p; a += std::fabs(p); }
+                if (!(std::fabs(double(y[r]) - s) <= (double(Ap[r + 1] - Ap[r]) + 2) * std::ldexp(1.0, -24) * a)) ++bad;
+            }
+            std::printf("[%-15s] gpus=%d %s bad_rows=%d\n", label, gpus, version ? "rewritten in place" : "first matrix", bad);
+            failures += bad ? 1 : 0;
+        }
+        mi355_host::dist_release();
+    }
+    HIP_OK(hipFree(dAp)); HIP_OK(hipFree(dAj)); HIP_OK(hipFree(dAx)); HIP_OK(hipFree(dX)); HIP_OK(hipFree(dY));
+    std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
+    return failures ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
     HIP_OK(hipSetDevice(0));  // USED_DEVICE 0 (common.cuh:8)
+    if (argc > 1 && std::strcmp(argv[1], "--dist-rewrite") == 0) return run_dist_rewrite(argc > 2 ? std::atoi(argv[2]) : 1);
     if (argc > 1 && std::strcmp(argv[1], "--bad-label") == 0) {
         int* d;
         HIP_OK(hipMalloc((void**)&d, 64));

@@ -35,6 +35,24 @@ def test_library_exports_every_declared_symbol(sp):
     assert set(sp.capi.EXPORTS) == decl
 
 
+def test_loader_library_exports_every_declared_symbol_and_loads_a_fixture(sp):
+    """include/mi355_load.h (libmi355load.so, host only): exports == declarations; a golden fixture loads to the
+    arrays tests/golden/golden.json holds (the reference's own LoadCoo + ToCsr made them, oracle/make_golden.py)."""
+    import json
+    text = open(os.path.join(ROOT, "include", "mi355_load.h")).read()
+    decl = set(re.findall(r"\b(mi355_(?:load|csr_host)[A-Za-z_0-9]*)\s*\(", text))
+    lib = sp.load.lib()
+    assert decl == set(sp.load.EXPORTS) and all(hasattr(lib, s) for s in decl), decl
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+    for name, case in gold.items():
+        st = case["struct"]
+        m = sp.load.load_mtx(os.path.join(ROOT, "tests", "golden", name))
+        assert (m.n_rows, m.n_cols, m.nnz) == (st["n_rows"], st["n_cols"], st["nnz"]), name
+        assert m.Ap.tolist() == st["Ap"] and m.Aj.tolist() == st["Aj"], name
+    with pytest.raises(RuntimeError, match="could not be opened"):
+        sp.load.load_mtx("/nonexistent/none.mtx")
+
+
 def test_version_and_status_strings(sp):
     lib = sp.capi.lib()
     assert lib.mi355_spmv_version() == 300

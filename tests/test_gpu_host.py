@@ -36,6 +36,22 @@ def test_cpp_boundary_all_labels_and_types():
     assert r.stdout.count("[genl on int    ]") == 2          # (+,*) and (min,+) on 32-bit integer values, 64-bit offsets
 
 
+@pytest.mark.parametrize("gpus", [1, 3])
+def test_cpp_dist_kinds_see_a_matrix_rewritten_in_place(gpus):
+    """hip_dist_* keep a handle holding copies of the structure; SpMV(kind, ...) must still read its arrays on every
+    call: the second call runs on another matrix, other values and another x at the SAME addresses and sizes.
+    gpus = 3: three "GPUs" on the one device through the emulated RCCL (tests/cpp/fake_rccl.cpp)."""
+    _build_exe()
+    env = dict(os.environ)
+    if gpus > 1:
+        env.update(MI355_SPMV_RCCL_LIB=os.path.join(ROOT, "tests", "cpp", "libfakerccl.so"), MI355_DIST_SHARED_DEVICE="1",
+                   MI355_DIST_TRIALS="1")
+    r = subprocess.run([EXE, "--dist-rewrite", str(gpus)], capture_output=True, text=True, timeout=300, env=env)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("rewritten in place bad_rows=0") == 3
+
+
 def test_cpp_boundary_unknown_label_exits_like_the_reference():
     """spmv.h:46-47: message on stderr and exit(EXIT_FAILURE)."""
     _build_exe()
