@@ -379,13 +379,13 @@ __device__ __forceinline__ void load_group(int32_t j, int32_t nnz, const int32_t
 // The caller has put a barrier between the last write of s_y and this.
 template <int BLOCK, typename val_t>
 __device__ __forceinline__ void store_chunk_results(const ChunkScratch<val_t>& scr, val_t* __restrict__ y,
-                                                    int64_t chunk_begin, int rows) {
+                                                    int64_t chunk_begin, int rows, int tid_known = -1) {
     val_t* const yc = y + chunk_begin;
     constexpr int PER16 = 16 / int(sizeof(val_t));
     const val_t alpha = scr.alpha, beta = scr.beta;
     const bool scaled = (alpha != val_t(1)) || (beta != val_t(0));   // uniform
     const int n_store = scr.store_rows >= 0 ? scr.store_rows : rows;
-    int tid = threadIdx.x;
+    int tid = tid_known >= 0 ? tid_known : int(threadIdx.x);   // (a caller that has rebuilt the index passes it: chunk_rows)
     asm volatile("" : "+v"(tid));   // (opaque: keeps the sweep's per-thread offsets from being hoisted out of a persistent loop)
     if (!scaled && (reinterpret_cast<uintptr_t>(yc) & 15u) == 0) {
         using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
@@ -461,33 +461,45 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
 #else
     auto row_of = [&](int g, int r) { return g * STRIDE + wave_rows0 + r * VW + row_in_wave; };
 #endif
+    // A register set holds the loaded columns and values only: the rows' bounds are read from LDS again when the group
+    // is consumed (2 R ds_reads) instead of riding along through the previous group's arithmetic — 2 R registers per
+    // set that the wide fp32 bodies, held to 128, do not have (they spilled).
     struct Group {
-        off_t lo[R], hi[R];   // bounds of the vector's R rows
-        off_t j[R];           // first element of this lane's step-0 group
         int4v c[R];
         v4 a[R];
     };
-    // issue the step-0 loads of group g (g may be past the end: rows clamp to empty)
-    auto issue = [&](int g, Group& G) {
+    struct Bounds { off_t lo[R], hi[R]; };
+    auto read_bounds = [&](int g, Bounds& B) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = row_of(g, r);
-            G.lo[r] = scr.s_b[min(row, rows)];
-            G.hi[r] = scr.s_b[min(row + 1, rows)];
+            B.lo[r] = scr.s_b[min(row, rows)];
+            B.hi[r] = scr.s_b[min(row + 1, rows)];
         }
+    };
+    auto step0 = [&](off_t lo) { return (lo & ~off_t(3)) + off_t(lane) * 4; };   // first element of this lane's step-0 group
+    // issue the step-0 loads of group g (g may be past the end: rows clamp to empty)
+    auto issue = [&](int g, Group& G) {
+        Bounds B;
+        read_bounds(g, B);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            G.j[r] = (G.lo[r] & ~off_t(3)) + off_t(lane) * 4;
-            off_t jl = G.j[r] < G.hi[r] ? G.j[r] : (G.lo[r] & ~off_t(3));
+            const off_t j0 = step0(B.lo[r]);
+            off_t jl = j0 < B.hi[r] ? j0 : (B.lo[r] & ~off_t(3));
             jl = jl < j_max ? jl : j_max;
             // straight-line, branch-free: hipcc serialises (vmcnt(0)) around loads in branches
             G.c[r] = stream_load(reinterpret_cast<const int4v*>(Aj + jl));
             G.a[r] = stream_load(reinterpret_cast<const v4*>(Ax + jl));
         }
+        // (nothing of the consume that follows may be scheduled above these loads: its first instructions wait for the
+        // PREVIOUS group's data, and a load issued behind that wait has lost its head start — seen as s_waitcnt vmcnt(6)
+        // in front of the eight prefetch loads, S32-band 177 -> 187 us)
+        __builtin_amdgcn_sched_barrier(0);
     };
     // DEPTH register sets in a ring: the loads of DEPTH - 1 groups are in flight while one is reduced.
     // (measured with 4 / 3 sets for the fp32 / fp64 R = 2 bodies: cant stand-in 11.3 -> 12.6 us, C4 stand-in 541 -> 602 us:
     // the extra sets cost more occupancy than the deeper prefetch buys; two everywhere)
+    // (round 3, C4 stand-in with 3 sets and 168 registers, which its LDS-bound three workgroups per CU allow: 585 -> 602 us)
     constexpr int DEPTH = 2;
     Group G[DEPTH];
 #pragma unroll
@@ -495,42 +507,67 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     const auto win = stage();     // (workgroup barrier inside)
 
     // sum += a[e] * x[c[e]] for the elements k = j+e inside [lo, hi).  WINDOW: x comes from the
-    // LDS window (unconditional ds_read at a clamped address + select); the rare column
-    // outside it is fetched and consumed under ONE branch per 4 elements, so the common path
-    // never waits on vector memory.  !WINDOW: plain gathers (masked elements hold a legal
-    // column of a neighbouring row, or 0, so the address is always in range).
-    auto accumulate = [&](val_t& sum, const int4v& c, const v4& a, off_t j, off_t lo, off_t hi) {
+    // LDS window: FOUR unconditional ds_reads at clamped addresses, issued back to back, then an fma and a select per
+    // element; the rare column outside the window is fetched and consumed under ONE branch per 4 elements, so the
+    // common path never waits on vector memory.  The values pass through an empty volatile asm (pin4), i.e. the reads
+    // happen whatever the comparisons say: left alone, hipcc sinks each read into its select and emits a BRANCH per
+    // element — s_and_saveexec, ds_read, s_waitcnt lgkmcnt(0), v_fmac, s_or exec: sixteen dependent LDS round trips
+    // per group of the fp32 body, one after the other (rounds 1-2 shipped exactly that; S32-band 178 -> 1xx us once
+    // the reads overlap).  !WINDOW: plain gathers (masked elements hold a legal column of a neighbouring row, or 0,
+    // so the address is always in range), pinned the same way.
+    auto pin4 = [](val_t (&v)[4]) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); };
+    // the window part of a step: lookups and reads only (no use of the values) ...
+    auto gather4 = [&](const int4v& c, val_t (&xv)[4], bool (&in)[4]) {
+        if constexpr (WINDOW) {
+            unsigned idx[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) in[e] = win.find(c[e], idx[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = win.s_x[idx[e]];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { in[e] = true; xv[e] = x[c[e]]; }
+        }
+    };
+    // ... and the arithmetic on values that have been pinned
+    // (branch-free on purpose: masks are combined with & / |, never && / ||, and every product is formed
+    // unconditionally and pinned before its select — written as `(valid && in) ? sum + a * xv : sum` hipcc lowers each
+    // element to exec-mask control flow, ~10 scalar instructions around one v_fma)
+    auto fold4 = [&](val_t& sum, const int4v& c, const v4& a, const val_t (&xv)[4], const bool (&in)[4], off_t j, off_t lo, off_t hi) {
         const off_t d_lo = lo - j, d_hi = hi - j;
         const int e_lo = d_lo > 0 ? int(d_lo) : 0;                 // lo - j <= 3 wherever this is called
         const int e_hi = d_hi < 4 ? (d_hi > 0 ? int(d_hi) : 0) : 4;
-        if constexpr (WINDOW) {
-            bool need[4];
-            bool any_need = false;
+        bool need_any = false;
+        bool need[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool valid = (e >= e_lo) & (e < e_hi);
-                unsigned idx;
-                const bool in = win.find(c[e], idx);
-                const val_t xv = win.s_x[idx];
-                sum = (valid && in) ? (sum + a[e] * xv) : sum;
-                need[e] = valid && !in;
-                any_need |= need[e];
-            }
-            if (any_need) {
+        for (int e = 0; e < 4; ++e) {
+            const bool valid = bool(int(e >= e_lo) & int(e < e_hi));
+            const bool use = bool(int(valid) & int(in[e]));
+            val_t t = sum + a[e] * xv[e];
+            asm volatile("" : "+v"(t));
+            sum = use ? t : sum;
+            need[e] = bool(int(valid) & int(!in[e]));
+            need_any = bool(int(need_any) | int(need[e]));
+        }
+        if constexpr (WINDOW) {
+            if (need_any) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (need[e]) sum += a[e] * x[c[e]];
                 }
             }
-        } else {
-            val_t xv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xv[e] = x[c[e]];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sum = ((e >= e_lo) & (e < e_hi)) ? (sum + a[e] * xv[e]) : sum;
         }
     };
+    auto accumulate = [&](val_t& sum, const int4v& c, const v4& a, off_t j, off_t lo, off_t hi) {
+        val_t xv[4];
+        bool in[4];
+        gather4(c, xv, in);
+        pin4(xv);
+        fold4(sum, c, a, xv, in, j, lo, hi);
+    };
     auto consume = [&](int g, const Group& G) {
+        Bounds B;
+        read_bounds(g, B);
         val_t sum[R];
         off_t jn[R], hi[R];
         bool deferred[R];
@@ -539,21 +576,37 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
         for (int r = 0; r < R; ++r) {
             // (uniform over the T lanes of the vector; a giant row always takes the long-row path, where it is
             // zeroed for the slice kernels, whatever the long-steps knob says)
-            const off_t len_r = G.hi[r] - G.lo[r];
+            const off_t len_r = B.hi[r] - B.lo[r];
             deferred[r] = len_r > LONG || (scr.giant_len > 0 && int64_t(len_r) > scr.giant_len);
             // the 16-byte path covers elements below nnz_vec; a long row is left to pass 2
-            hi[r] = deferred[r] ? G.lo[r] : (G.hi[r] < nnz_vec ? G.hi[r] : nnz_vec);
+            hi[r] = deferred[r] ? B.lo[r] : (B.hi[r] < nnz_vec ? B.hi[r] : nnz_vec);
             sum[r] = val_t(0);
-            accumulate(sum[r], G.c[r], G.a[r], G.j[r], G.lo[r], hi[r]);
-            jn[r] = G.j[r] + off_t(T) * 4;
-            more |= jn[r] < hi[r];
+        }
+        // the window reads of XB rows (8 values) in flight at once, then their arithmetic
+        constexpr int XB = R >= 2 ? 2 : 1;
+#pragma unroll
+        for (int r0 = 0; r0 < R; r0 += XB) {
+            val_t xv[XB][4];
+            bool in[XB][4];
+#pragma unroll
+            for (int b = 0; b < XB; ++b) gather4(G.c[r0 + b], xv[b], in[b]);
+#pragma unroll
+            for (int b = 0; b < XB; ++b) pin4(xv[b]);
+#pragma unroll
+            for (int b = 0; b < XB; ++b) {
+                const int r = r0 + b;
+                const off_t j0 = step0(B.lo[r]);
+                fold4(sum[r], G.c[r], G.a[r], xv[b], in[b], j0, B.lo[r], hi[r]);
+                jn[r] = j0 + off_t(T) * 4;
+                more |= jn[r] < hi[r];
+            }
         }
         while (more) {                                     // rows longer than one step (4T nonzeros)
             int4v c2[R];
             v4 a2[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                off_t jl = jn[r] < hi[r] ? jn[r] : (G.lo[r] & ~off_t(3));
+                off_t jl = jn[r] < hi[r] ? jn[r] : (B.lo[r] & ~off_t(3));
                 jl = jl < j_max ? jl : j_max;
                 c2[r] = stream_load(reinterpret_cast<const int4v*>(Aj + jl));
                 a2[r] = stream_load(reinterpret_cast<const v4*>(Ax + jl));
@@ -561,7 +614,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
             more = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                accumulate(sum[r], c2[r], a2[r], jn[r], G.lo[r], hi[r]);   // (clamped loads are masked by hi)
+                accumulate(sum[r], c2[r], a2[r], jn[r], B.lo[r], hi[r]);   // (clamped loads are masked by hi)
                 jn[r] += off_t(T) * 4;
                 more |= jn[r] < hi[r];
             }
@@ -579,8 +632,8 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
                     atomicOr(&scr.long_map[rel >> 5], 1u << (rel & 31));
                     continue;
                 }
-                if (G.hi[r] > nnz_vec) {                   // the last (partial) group of the arrays
-                    for (off_t k = (G.lo[r] > nnz_vec ? G.lo[r] : nnz_vec); k < G.hi[r]; ++k)
+                if (B.hi[r] > nnz_vec) {                   // the last (partial) group of the arrays
+                    for (off_t k = (B.lo[r] > nnz_vec ? B.lo[r] : nnz_vec); k < B.hi[r]; ++k)
                         sum[r] += Ax[k] * x[Aj[k]];
                 }
                 scr.s_y[row] = sum[r];
@@ -611,6 +664,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     __syncthreads();
     const int lane64 = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
+    const int tid2 = threadIdx.x;
     const int words = (rows + 31) >> 5;
     int turn = 0;                                   // marked rows are dealt to the waves in turn
     bool any_huge = false;                          // same in every thread: it depends on LDS contents only
@@ -655,7 +709,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
                 const off_t start = scr.s_b[local], end = scr.s_b[local + 1];
                 if (end - start <= off_t(kHugeRow)) continue;            // uniform over the workgroup
                 if (scr.giant_len > 0 && int64_t(end - start) > scr.giant_len) {   // split across workgroups elsewhere
-                    if (threadIdx.x == 0) scr.s_y[local] = val_t(0);
+                    if (tid2 == 0) scr.s_y[local] = val_t(0);
                     continue;
                 }
                 // the main loop's pipeline again: R slabs of BLOCK x 4 nonzeros in flight, the next
@@ -669,7 +723,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
                 auto issue_slabs = [&](int64_t it, Slabs& S) {
 #pragma unroll
                     for (int u = 0; u < R; ++u) {
-                        const int64_t j = it + u * SLAB + int64_t(threadIdx.x) * 4;
+                        const int64_t j = it + u * SLAB + int64_t(tid2) * 4;
                         off_t jl = j < int64_t(hi_v) ? off_t(j) : first;
                         jl = jl < j_max ? jl : j_max;
                         S.c[u] = stream_load(reinterpret_cast<const int4v*>(Aj + jl));
@@ -679,7 +733,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
                 auto eat_slabs = [&](int64_t it, const Slabs& S) {
 #pragma unroll
                     for (int u = 0; u < R; ++u) {
-                        const int64_t j = it + u * SLAB + int64_t(threadIdx.x) * 4;
+                        const int64_t j = it + u * SLAB + int64_t(tid2) * 4;
                         accumulate(sum, S.c[u], S.a[u], j < int64_t(hi_v) ? off_t(j) : hi_v, start, hi_v);
                     }
                 };
@@ -693,12 +747,12 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
                         eat_slabs(it + R * SLAB, S1);
                     }
                 }
-                if (threadIdx.x == 0 && end > nnz_vec)                           // the arrays' last, partial group
+                if (tid2 == 0 && end > nnz_vec)                                  // the arrays' last, partial group
                     for (off_t k = (start > nnz_vec ? start : nnz_vec); k < end; ++k) sum += Ax[k] * x[Aj[k]];
                 sum = vector_reduce<kWave, val_t>(sum);
                 if (lane64 == 0) s_part[wave] = sum;
                 __syncthreads();
-                if (threadIdx.x == 0) {
+                if (tid2 == 0) {
                     val_t total = s_part[0];
 #pragma unroll
                     for (int i = 1; i < WAVES; ++i) total += s_part[i];
@@ -710,7 +764,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     }
 
     __syncthreads();
-    store_chunk_results<BLOCK, val_t>(scr, y, chunk_begin, rows);
+    store_chunk_results<BLOCK, val_t>(scr, y, chunk_begin, rows, tid2);
 }
 
 // chunk_rows with the vector width chosen PER CHUNK (nnz-balanced plans): a power-law matrix has chunks of

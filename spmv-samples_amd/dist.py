@@ -123,3 +123,83 @@ def allgatherv(y_local, y_full, cuts, group=None, async_op=False):
     for w in works:
         w.wait()
     return y_full
+
+
+# ---- the three allgatherv exchanges of csrc/dist.hip, restated ------------------------------------------------
+# mi355_spmv_dist_* makes the allgatherv of sub-block s in one of three ways (include/mi355_spmv.h,
+# MI355_DIST_EXCHANGE_*).  exchange_schedule is the same count / displacement logic as plain data — what each rank
+# calls, in order — so that it can be checked without a GPU (tests/test_dist_cpu.py runs it over gloo with 2 and 3
+# ranks) and against the calls the library really makes (tests/test_gpu_dist_multi.py reads them back from the
+# emulated RCCL).  Block g = rank * sub_blocks + s holds rows [row_cuts[g], row_cuts[g + 1]).
+def exchange_schedule(row_cuts, world, sub_blocks, s, mode, rank):
+    """The calls of `rank` for sub-block s: a list of tuples
+         ("bcast", root, first_row, count)            in-place broadcast of block (root, s)
+         ("send", peer, first_row, count) / ("recv", peer, first_row, count)
+         ("allgather_in_place", first_row_of_rank_0s_block, count)
+         ("pack", first_row, count, slot) ("allgather_padded", pad) ("unpack", first_row, count, slot) ...
+    """
+    blk = lambda r: r * sub_blocks + s
+    rows = lambda r: row_cuts[blk(r) + 1] - row_cuts[blk(r)]
+    if mode == "bcast":
+        return [("bcast", r, row_cuts[blk(r)], rows(r)) for r in range(world) if rows(r) > 0]
+    if mode == "sendrecv":
+        out = []
+        for r in range(world):
+            if r == rank:
+                continue
+            if rows(rank) > 0:
+                out.append(("send", r, row_cuts[blk(rank)], rows(rank)))
+            if rows(r) > 0:
+                out.append(("recv", r, row_cuts[blk(r)], rows(r)))
+        return out
+    if mode == "allgather":
+        cnt = rows(0)
+        if cnt > 0 and all(rows(r) == cnt and row_cuts[blk(r)] == row_cuts[blk(0)] + r * cnt for r in range(world)):
+            return [("allgather_in_place", row_cuts[blk(0)], cnt)]
+        widest = max(row_cuts[g + 1] - row_cuts[g] for g in range(world * sub_blocks))
+        pad = (widest + 3) & ~3
+        out = []
+        if rows(rank) > 0:
+            out.append(("pack", row_cuts[blk(rank)], rows(rank), rank))
+        out.append(("allgather_padded", pad))
+        out += [("unpack", row_cuts[blk(r)], rows(r), r) for r in range(world) if r != rank and rows(r) > 0]
+        return out
+    raise ValueError(mode)
+
+
+def exchange_sub_block(y_full, row_cuts, world, sub_blocks, s, mode, group=None):
+    """Run exchange_schedule with torch.distributed on this rank's full-length y (blocking)."""
+    rank = dist.get_rank(group)
+    sched = exchange_schedule(row_cuts, world, sub_blocks, s, mode, rank)
+    works, stage = [], None
+    for op in sched:
+        if op[0] == "bcast":
+            _, root, first, cnt = op
+            works.append(dist.broadcast(y_full[first:first + cnt], src=root, group=group, async_op=True))
+        elif op[0] == "send":
+            _, peer, first, cnt = op
+            works.append(dist.isend(y_full[first:first + cnt].contiguous(), dst=peer, group=group))
+        elif op[0] == "recv":
+            _, peer, first, cnt = op
+            works.append(dist.irecv(y_full[first:first + cnt], src=peer, group=group))
+        elif op[0] == "allgather_in_place":
+            _, first, cnt = op
+            out = y_full[first:first + world * cnt]
+            dist.all_gather_into_tensor(out, out[rank * cnt:(rank + 1) * cnt].clone(), group=group)
+        elif op[0] == "pack":
+            _, first, cnt, slot = op
+            pad = next(o[1] for o in sched if o[0] == "allgather_padded")
+            stage = torch.zeros(world * pad, dtype=y_full.dtype, device=y_full.device)
+            stage[slot * pad:slot * pad + cnt] = y_full[first:first + cnt]
+        elif op[0] == "allgather_padded":
+            pad = op[1]
+            if stage is None:
+                stage = torch.zeros(world * pad, dtype=y_full.dtype, device=y_full.device)
+            dist.all_gather_into_tensor(stage, stage[rank * pad:(rank + 1) * pad].clone(), group=group)
+        elif op[0] == "unpack":
+            _, first, cnt, slot = op
+            pad = stage.numel() // world
+            y_full[first:first + cnt] = stage[slot * pad:slot * pad + cnt]
+    for w in works:
+        w.wait()
+    return y_full

@@ -193,3 +193,53 @@ def test_allgatherv_equal_counts_world2_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker_equal, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert sorted(os.listdir(tmp_path)) == ["rank0.ok", "rank1.ok"]
+
+
+def _worker_exchanges(rank, world, port, out_dir):
+    """The count / displacement logic of the library's three exchanges (csrc/dist.hip exchange_sub_block, restated in
+    dist.exchange_schedule) over gloo: every GPU's rows in 3 sub-blocks, uneven blocks, an EMPTY block, then equal
+    adjacent blocks (the in-place all-gather)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    sp = g.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    for case in ("uneven", "equal"):
+        sub = 3 if case == "uneven" else 1
+        if case == "uneven":
+            sizes = [((7 * g_ + 3) % 11) * 4 for g_ in range(world * sub)]      # multiples of 4 rows, one of them 0
+            sizes[1] = 0
+        else:
+            sizes = [24] * world
+        cuts = [0]
+        for n in sizes:
+            cuts.append(cuts[-1] + n)
+        want = torch.arange(cuts[-1], dtype=torch.float32) * 0.5 + 1
+        for mode in ("bcast", "sendrecv", "allgather"):
+            y = torch.full((cuts[-1],), float("nan"))
+            for s in range(sub):                                               # "compute" this rank's blocks
+                b = rank * sub + s
+                y[cuts[b]:cuts[b + 1]] = want[cuts[b]:cuts[b + 1]]
+            for s in range(sub):
+                sp.dist.exchange_sub_block(y, cuts, world, sub, s, mode)
+            ok = ok and torch.equal(y, want)
+            sched = sp.dist.exchange_schedule(cuts, world, sub, 0, mode, rank)
+            if case == "equal" and mode == "allgather":
+                ok = ok and sched == [("allgather_in_place", 0, 24)]
+            if case == "uneven" and mode == "allgather":
+                ok = ok and sched[0][0] in ("pack", "allgather_padded") and any(o[0] == "allgather_padded" and o[1] % 4 == 0 and o[1] >= max(sizes) for o in sched)
+            if mode == "bcast":
+                ok = ok and [o[1] for o in sched] == [r for r in range(world) if sizes[r * sub] > 0]
+    open(os.path.join(out_dir, "rank%d.%s" % (rank, "ok" if ok else "bad")), "w").close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_three_exchanges_counts_and_displacements_gloo(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_worker_exchanges, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["rank%d.ok" % r for r in range(world)]

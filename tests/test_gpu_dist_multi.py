@@ -138,40 +138,60 @@ def test_values_and_x_are_handed_over_on_every_call(sp, matrices):
     d.destroy()
 
 
-def test_broadcast_schedule_roots_counts_and_displacements(sp, emulated_rccl, matrices):
-    """What the grouped in-place broadcasts are called with: for every sub-block s and GPU i, one ncclBroadcast per
-    non-empty block (root, s) with root = owner, count = the block's rows, send == recv == that GPU's y + first row."""
-    name, m = matrices[1]
-    gpus, sub = 3, 2
+@pytest.mark.parametrize("which", [1, 0])
+def test_exchange_calls_match_the_restated_schedule(sp, emulated_rccl, matrices, which):
+    """What RCCL is called with, read back from the emulation's log, against dist.exchange_schedule (the same count /
+    displacement logic in Python, which the CPU suite runs over gloo): roots, peers, counts, pointers, order — for the
+    grouped in-place broadcasts, the send / recv pairs, and the all-gather (padded through staging on the R-MAT's
+    uneven blocks, in place on the band's equal ones)."""
+    name, m = matrices[which]
+    gpus, sub = (3, 2) if which == 1 else (4, 1)
+    vb = m.Ax.element_size()
     x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 43, DEV)
     d = sp.DistPlan.local("vector", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype, devices=[0] * gpus, sub_blocks=sub)
-    d.set_exchange("bcast")
     cuts = d.cuts()
     y = torch.empty(m.n_rows, dtype=m.Ax.dtype, device=DEV)
-    torch.cuda.synchronize()
-    emulated_rccl.fake_rccl_log_clear()
-    d.execute(m.Ax, x, y)
-    torch.cuda.synchronize()
-    n = emulated_rccl.fake_rccl_log_size()
-    rec = (C.c_longlong * 6)()
-    calls = []
-    for i in range(n):
-        assert emulated_rccl.fake_rccl_log_get(i, rec) == 0
-        calls.append(tuple(rec))
     lib = sp.capi.lib()
     base = {0: y.data_ptr()}
     for i in range(1, gpus):
         base[i] = lib.mi355_spmv_dist_device_y(d._h, i)
-    expect = []
-    for s in range(sub):
-        for i in range(gpus):
-            for root in range(gpus):
-                g = root * sub + s
-                cnt = cuts[g + 1] - cuts[g]
-                if cnt > 0:
-                    at = base[i] + cuts[g] * 4
-                    expect.append((1, i, root, cnt, at, at))
-    assert calls == expect
+    for mode in EXCHANGES:
+        d.set_exchange(mode)
+        torch.cuda.synchronize()
+        emulated_rccl.fake_rccl_log_clear()
+        d.execute(m.Ax, x, y)
+        torch.cuda.synchronize()
+        rec = (C.c_longlong * 6)()
+        calls = []
+        for i in range(emulated_rccl.fake_rccl_log_size()):
+            assert emulated_rccl.fake_rccl_log_get(i, rec) == 0
+            calls.append(tuple(rec))
+        expect, padded = [], []
+        for s in range(sub):
+            for i in range(gpus):
+                for op in sp.dist.exchange_schedule(cuts, gpus, sub, s, mode, i):
+                    if op[0] == "bcast":
+                        at = base[i] + op[2] * vb
+                        expect.append((1, i, op[1], op[3], at, at))
+                    elif op[0] == "send":
+                        expect.append((2, i, op[1], op[3], base[i] + op[2] * vb, 0))
+                    elif op[0] == "recv":
+                        expect.append((3, i, op[1], op[3], 0, base[i] + op[2] * vb))
+                    elif op[0] == "allgather_in_place":
+                        at = base[i] + op[1] * vb
+                        expect.append((4, i, -1, op[2], at + i * op[2] * vb, at))
+                    elif op[0] == "allgather_padded":
+                        expect.append((4, i, -1, op[1], None, None))
+                        padded.append(len(expect) - 1)
+        assert len(calls) == len(expect), (mode, len(calls), len(expect))
+        for k, (got, want) in enumerate(zip(calls, expect)):
+            if k in padded:                      # staging buffer: its address is the library's, its layout is not
+                assert got[:4] == want[:4] and got[4] == got[5] + got[1] * got[3] * vb, (mode, k, got)
+            else:
+                assert got == want, (mode, k, got, want)
+        if mode == "allgather":
+            assert (d.dist_info()["allgather_in_place"] == 1) == (not padded)
+            assert which == 0 or len(padded) == sub * gpus          # R-MAT: nnz-balanced blocks differ in rows
     d.destroy()
 
 
