@@ -692,6 +692,16 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide, bool allow_huge)
         const bool long_chunk = p.rows_per_chunk * mean >= 49152 || rows_before_rounding >= kMaxChunkRows;
         // (a forced 512 is honoured unless the window needs several bands: those kernels exist for 256 threads only)
         if ((force && p.n_seg < 2) || (long_chunk && p.window_elems > 0 && p.n_seg < 2 && p.window_from_band)) return;
+        // A small matrix whose chunks all run at once — one round of the chip — also keeps the 512 threads when its rows
+        // are long (16+ lanes per row: the R = 2 bodies): the same rows by half as many workgroups, i.e. half the
+        // prologues (bounds, window, barriers) in a kernel that is nothing but its prologue and four groups of rows.
+        // cant stand-in: 10.7-10.8 us against 10.9-11.2 with 976 workgroups of 256 (rounds 2 and 3, three boxes).
+        {
+            const int64_t n_chunks = p.rows_per_chunk > 0 ? (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk : 0;
+            if (!force && p.lanes_per_row >= 16 && p.window_elems > 0 && p.n_seg < 2 && p.window_from_band &&
+                n_chunks >= kCus && n_chunks <= int64_t(kCus) * 2)
+                return;
+        }
     }
     shape(kBlock, 32768);
     // (several bands with two 512-thread workgroups of 78 KB per CU and 1 664-row chunks: measured 722 vs 700 us on the
@@ -762,7 +772,7 @@ bool shape_sweep(Plan& p) {
     const int64_t band = p.band_hi - p.band_lo + 1;
     int t = p.lanes_per_row;
     while (t < kWave && 4 * t < p.probe_len_max) t *= 2;
-    const int64_t rows = int64_t(kHugeBlock / t) * kSweepRows;
+    const int64_t rows = int64_t(kHugeBlock / t) * sweep_rows_for(p.val_type, t);
     const int64_t fixed = int64_t(chunk_lds_bytes(0, int(rows), size_t(val_bytes)));
     const int64_t cap = ((155 * 1024 - fixed) / val_bytes) & ~int64_t(3);
     const int64_t span = band + rows + 8;

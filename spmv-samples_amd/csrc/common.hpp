@@ -25,7 +25,14 @@ inline int64_t giant_slice_for(int64_t giant_len) {
 }
 constexpr int kWideBlock = 512;      // VECTOR / LIGHT on big uniform matrices: 8 waves, chunks twice as long
 constexpr int kHugeBlock = 1024;     // VECTOR, band too wide for two workgroups per CU: ONE 16-wave workgroup with ~150 KB of LDS
-constexpr int kSweepRows = 4;        // rows a vector of the sweep kernel holds (its whole chunk stays in registers)
+constexpr int kSweepRows = 4;        // rows a vector of the sweep kernel holds at least (its whole chunk stays in registers)
+// ... and 8 for fp32 where a chunk of 8 rows per vector stays within the 2 048 rows a chunk may have (T >= 4): the
+// same window passes then serve twice the nonzeros — staging the band, not the Aj / Ax stream, is what a swept chunk
+// waits for (band of 65 537 columns, 2^22 rows x 32: 371 -> 321 us; 131 073 columns: 508 -> 411).  fp64 keeps 4: eight
+// rows of doubles do not fit the 128 registers a 1 024-thread workgroup has per lane.
+inline int sweep_rows_for(int val_type, int lanes_per_row) {
+    return (val_type == MI355_VAL_F32 && (kHugeBlock / lanes_per_row) * 8 <= 2048) ? 8 : kSweepRows;
+}
 constexpr int kXcds = 8;             // XCDs per MI355X, each with a private L2
 constexpr int kCus = 256;            // compute units per MI355X
 

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= kWideBlock || R == 2 ? 4 : 3)) voi
 
 // The band is wider than any window of x: one 1 024-thread workgroup per CU, a chunk = one group of rows held in
 // registers, the window sweeps the band (xwindow.hpp, chunk_rows_sweep).
-template <int T, typename val_t>
+template <int T, int R, typename val_t>
 __global__ __launch_bounds__(kHugeBlock, 4) void csr_vector_sweep_kernel(
     int32_t n_rows, int32_t n_cols, int64_t nnz, const ApView Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y, ChunkMap cmap,
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kHugeBlock, 4) void csr_vector_sweep_kernel(
     const int32_t nnz_c = int32_t(left < kRel32Limit + 32768 ? left : kRel32Limit + 32768);
     // (a persistent workgroup per CU walking its share of the chunks measured WORSE, 194 vs 187 us at two passes,
     // 438 vs 358 at seven: the hardware dispatcher's refill costs less than the registers the loop does)
-    chunk_rows_sweep<kHugeBlock, T, kSweepRows, val_t>(rb, re, nnz_c, Aj + base, Ax + base, x, y, n_cols, window_cap, hint, scr);
+    chunk_rows_sweep<kHugeBlock, T, R, val_t>(rb, re, nnz_c, Aj + base, Ax + base, x, y, n_cols, window_cap, hint, scr);
 }
 
 template <int T, typename off_t, typename val_t>
@@ -240,15 +240,25 @@ static int launch_vector_sweep(const Plan& p, const ApView Ap, const val_t* Ax, 
     const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(val_t));
     const ChunkMap cmap{nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, 0, int64_t(0),
                         p.knob.rel32_limit > 0 ? p.knob.rel32_limit : kRel32Limit, 0};
-    if (p.rows_per_chunk != int64_t(kHugeBlock / p.lanes_per_row) * kSweepRows || p.rows_cap < p.rows_per_chunk) {
+    // rows a vector holds: 4, or 8 (fp32; sweep_rows_for) — the plan's rows per chunk say which
+    const int64_t vectors = kHugeBlock / p.lanes_per_row;
+    const int held = int(p.rows_per_chunk / vectors);
+    constexpr bool kHasEight = sizeof(val_t) == 4;
+    if (p.rows_per_chunk != vectors * held || !(held == kSweepRows || (kHasEight && held == 8 && p.lanes_per_row >= 4)) ||
+        p.rows_cap < p.rows_per_chunk) {
         set_error("csr_vector: sweep plan with %lld rows per chunk at %d lanes per row", (long long)p.rows_per_chunk, p.lanes_per_row);
         return MI355_SPMV_EINVAL;
     }
+#define MI355_VEC_SWEEP(TT, RR)                                                                               \
+    do {                                                                                                      \
+        if (const int st = allow_dynamic_lds((const void*)csr_vector_sweep_kernel<TT, RR, val_t>, lds)) return st; \
+        hipLaunchKernelGGL((csr_vector_sweep_kernel<TT, RR, val_t>), grid, block, lds, s, p.n_rows, p.n_cols, p.nnz_read, Ap, \
+                           p.Aj, Ax, x, y, cmap, (int32_t)p.window_elems, hint, (val_t)p.alpha, (val_t)p.beta);   \
+    } while (0)
 #define MI355_VEC_CASE(TT)                                                                                    \
     case TT:                                                                                                  \
-        if (const int st = allow_dynamic_lds((const void*)csr_vector_sweep_kernel<TT, val_t>, lds)) return st; \
-        hipLaunchKernelGGL((csr_vector_sweep_kernel<TT, val_t>), grid, block, lds, s, p.n_rows, p.n_cols, p.nnz_read, Ap, \
-                           p.Aj, Ax, x, y, cmap, (int32_t)p.window_elems, hint, (val_t)p.alpha, (val_t)p.beta);   \
+        if constexpr (kHasEight && TT >= 4) { if (held == 8) { MI355_VEC_SWEEP(TT, 8); break; } }              \
+        MI355_VEC_SWEEP(TT, kSweepRows);                                                                      \
         break;
     switch (p.lanes_per_row) {
         MI355_VEC_CASE(2)
@@ -262,6 +272,7 @@ static int launch_vector_sweep(const Plan& p, const ApView Ap, const val_t* Ax, 
             return MI355_SPMV_EINVAL;
     }
 #undef MI355_VEC_CASE
+#undef MI355_VEC_SWEEP
     MI355_HIP_TRY(hipGetLastError());
     return MI355_SPMV_OK;
 }

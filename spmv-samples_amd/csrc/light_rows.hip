@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void light_rows_kernel(
 // The band is wider than any window of x (xwindow.hpp, chunk_rows_sweep; csr_vector.hip has the static twin): one
 // 1 024-thread workgroup per CU, a chunk = one group of rows held in registers, handed out by the counters exactly
 // as the equal-row chunks of light_rows_window_kernel are (one dequeue per workgroup).
-template <int T, typename val_t>
+template <int T, int R, typename val_t>
 __global__ __launch_bounds__(kHugeBlock, 4) void light_rows_sweep_kernel(
     int32_t n_rows, int32_t n_cols, int64_t nnz, const ApView Ap, const int32_t* __restrict__ Aj,
     const val_t* __restrict__ Ax, const val_t* __restrict__ x, val_t* __restrict__ y,
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kHugeBlock, 4) void light_rows_sweep_kernel(
             __syncthreads();
             const int64_t left = nnz - base;
             const int32_t nnz_c = int32_t(left < kRel32Limit + 32768 ? left : kRel32Limit + 32768);
-            chunk_rows_sweep<kHugeBlock, T, kSweepRows, val_t>(rb, re, nnz_c, Aj + base, Ax + base, x, y, n_cols, window_cap, hint, scr);
+            chunk_rows_sweep<kHugeBlock, T, R, val_t>(rb, re, nnz_c, Aj + base, Ax + base, x, y, n_cols, window_cap, hint, scr);
         }
     }
     if (!static_mode) light_leave(counters);
@@ -482,15 +482,24 @@ static int launch_light_sweep(const Plan& p, const ApView Ap, const val_t* Ax, c
     const size_t lds = chunk_lds_bytes(p.window_elems, p.rows_cap, sizeof(val_t));
     const ChunkMap cmap{nullptr, (int32_t)p.rows_per_chunk, (int32_t)p.rows_cap, p.n_chunks, 0, int64_t(0),
                         p.knob.rel32_limit > 0 ? p.knob.rel32_limit : kRel32Limit, p.light_dequeue_once ? 1 : 0};
-    if (p.rows_per_chunk != int64_t(kHugeBlock / p.lanes_per_row) * kSweepRows || p.rows_cap < p.rows_per_chunk) {
+    const int64_t vectors = kHugeBlock / p.lanes_per_row;     // (rows a vector holds: 4, or 8 in fp32 — csr_vector.hip, sweep_rows_for)
+    const int held = int(p.rows_per_chunk / vectors);
+    constexpr bool kHasEight = sizeof(val_t) == 4;
+    if (p.rows_per_chunk != vectors * held || !(held == kSweepRows || (kHasEight && held == 8 && p.lanes_per_row >= 4)) ||
+        p.rows_cap < p.rows_per_chunk) {
         set_error("light_rows: sweep plan with %lld rows per chunk at %d lanes per row", (long long)p.rows_per_chunk, p.lanes_per_row);
         return MI355_SPMV_EINVAL;
     }
+#define MI355_LIGHT_SWEEP(TT, RR)                                                                              \
+    do {                                                                                                       \
+        if (const int st = allow_dynamic_lds((const void*)light_rows_sweep_kernel<TT, RR, val_t>, lds)) return st; \
+        hipLaunchKernelGGL((light_rows_sweep_kernel<TT, RR, val_t>), grid, block, lds, s, p.n_rows, p.n_cols, p.nnz_read, Ap, \
+                           p.Aj, Ax, x, y, p.counters, cmap, (int32_t)p.window_elems, hint, (val_t)p.alpha, (val_t)p.beta); \
+    } while (0)
 #define MI355_LIGHT_CASE(TT)                                                                                   \
     case TT:                                                                                                   \
-        if (const int st = allow_dynamic_lds((const void*)light_rows_sweep_kernel<TT, val_t>, lds)) return st; \
-        hipLaunchKernelGGL((light_rows_sweep_kernel<TT, val_t>), grid, block, lds, s, p.n_rows, p.n_cols, p.nnz_read, Ap, \
-                           p.Aj, Ax, x, y, p.counters, cmap, (int32_t)p.window_elems, hint, (val_t)p.alpha, (val_t)p.beta); \
+        if constexpr (kHasEight && TT >= 4) { if (held == 8) { MI355_LIGHT_SWEEP(TT, 8); break; } }             \
+        MI355_LIGHT_SWEEP(TT, kSweepRows);                                                                     \
         break;
     switch (p.lanes_per_row) {
         MI355_LIGHT_CASE(2)

@@ -801,7 +801,7 @@ __device__ __forceinline__ void chunk_rows_any(int64_t chunk_begin, int64_t chun
 
 // 16-byte loads a thread of the sweep (chunk_rows_sweep) keeps in flight while a window is staged: a window of
 // ~9 600 groups is one batch in fp32, two in fp64 (whose body holds 32 more registers of Ax).
-__host__ __device__ constexpr int sweep_loads(size_t val_bytes) { return val_bytes == 4 ? 10 : 5; }
+__host__ __device__ constexpr int sweep_loads(size_t val_bytes, int rows_held = 4) { return rows_held > 4 ? 4 : (val_bytes == 4 ? 10 : 5); }
 
 // A band too wide for ANY window (more columns than a CU's LDS holds): the window SWEEPS the band.
 // The plain gather is bound by line fills — every lane of a gather instruction pulls its own 128-byte line
@@ -827,7 +827,7 @@ __device__ __forceinline__ void chunk_rows_sweep(int64_t chunk_begin, int64_t ch
     using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
     constexpr int PER16 = 16 / int(sizeof(val_t));
     constexpr int VW = kWave / T;
-    constexpr int SWEEP_LOADS = sweep_loads(sizeof(val_t));
+    constexpr int SWEEP_LOADS = sweep_loads(sizeof(val_t), R);
     // (opaque copy of the thread index: inside the kernel's loop over chunks the optimiser otherwise hoists every
     // per-thread value below out of the loop, keeps them all live across the chunk and spills)
     int tid = threadIdx.x;
