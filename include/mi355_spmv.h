@@ -262,7 +262,9 @@ int mi355_spmv_plan_create_block(mi355_spmv_plan** plan, int kind, int off_type,
  *   execute(d, Ax, x, y, stream)   Ax = this rank's values (view described above), x = this GPU's copy of
  *                  x, y = this GPU's full-length y.
  * With one GPU (n_devices == 1 / world == 1) no communicator is made and execute is the blocks' plain
- * executes on the caller's stream.                                                                          */
+ * executes on the caller's stream.
+ * STATUS: world > 1 is EXPERIMENTAL — it has run only against an emulation of RCCL (several "GPUs" on one device,
+ * tests/cpp/fake_rccl.cpp): schedule, counts, displacements and stream order are tested, RCCL itself and xGMI are not. */
 typedef struct mi355_spmv_dist mi355_spmv_dist;
 int mi355_spmv_dist_create_local(mi355_spmv_dist** dist, int kind, int off_type, int val_type,
                                  int32_t n_rows, int32_t n_cols, int64_t nnz, const void* Ap,

@@ -28,6 +28,11 @@
 //                    an "ms" label (timer.hpp:10 vs main.cu:111-112); default keeps its label
 //   --ngpu N         GPUs the hip_dist_* kinds spread the rows over (default 1; the reference is
 //                    single-device, main.cu:53); --sub-blocks S = row blocks per GPU (default 4 when N > 1)
+// and, since no SuiteSparse file is at hand offline (SURVEY §5 "config / flags", §8(d)), a seeded matrix in the file's place:
+//     ./bin/spmv --synthetic band:n=4194304,k=32,w=4096 hip_vector hip_merge --seed 1
+//     ./bin/spmv synthetic:rand:n=1048576,k=16 hip_merge
+//   band: n rows, exactly k nonzeros per row, sorted columns sampled without replacement from [r - w, r + w] (the
+//         S32-band family of SURVEY §8(d)); rand: k columns uniform over [0, n); values U(-1, 1); --seed S (default 1).
 #include <hip/hip_runtime_api.h>
 
 #include <cmath>
@@ -57,14 +62,86 @@ struct Options {
     int iters = 2000;
     bool poison = true;
     bool unit_us = false;
+    unsigned long long seed = 1;
 };
+
+// ---- seeded synthetic matrices (in the place of a Matrix Market file) ----------------------------------------
+static unsigned long long mix(unsigned long long& s) {          // splitmix64
+    s += 0x9e3779b97f4a7c15ull;
+    unsigned long long z = s;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+template <typename index_t, typename offset_t, typename value_t>
+static csr_t<index_t, offset_t, value_t> make_synthetic(const std::string& spec, unsigned long long seed) {
+    const size_t colon = spec.find(':');
+    const std::string family = spec.substr(0, colon);
+    long long n = 1 << 20, k = 32, w = 4096;
+    if (colon != std::string::npos) {
+        std::string rest = spec.substr(colon + 1);
+        size_t pos = 0;
+        while (pos < rest.size()) {
+            const size_t comma = rest.find(',', pos);
+            const std::string item = rest.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+            const size_t eq = item.find('=');
+            if (eq == std::string::npos) { std::cerr << "synthetic spec: expected name=value, got " << item << std::endl; std::exit(1); }
+            const long long v = std::atoll(item.substr(eq + 1).c_str());
+            const std::string name = item.substr(0, eq);
+            if (name == "n") n = v; else if (name == "k") k = v; else if (name == "w") w = v;
+            else { std::cerr << "synthetic spec: unknown parameter " << name << std::endl; std::exit(1); }
+            if (comma == std::string::npos) break;
+            pos = comma + 1;
+        }
+    }
+    const bool band = family == "band";
+    if (!band && family != "rand") { std::cerr << "synthetic spec: family is band or rand" << std::endl; std::exit(1); }
+    if (n < 1 || k < 1 || k > n || (band && 2 * w + 1 < k) || n >= (1ll << 31) - 1) {
+        std::cerr << "synthetic spec: need 1 <= k <= n < 2^31 and, for band, 2 w + 1 >= k" << std::endl;
+        std::exit(1);
+    }
+    if (n * k >= (long long)std::numeric_limits<offset_t>::max()) { std::cerr << "synthetic spec: n * k does not fit offset_t (use --offset 64)" << std::endl; std::exit(1); }
+    csr_t<index_t, offset_t, value_t> csr;
+    csr.number_of_rows = index_t(n);
+    csr.number_of_columns = index_t(n);
+    csr.number_of_nonzeros = offset_t(n * k);
+    csr.row_offsets.resize(size_t(n) + 1);
+    csr.column_indices.resize(size_t(n * k));
+    csr.nonzero_values.resize(size_t(n * k));
+    std::vector<long long> cols(static_cast<size_t>(k));
+    for (long long r = 0; r <= n; ++r) csr.row_offsets[size_t(r)] = offset_t(r * k);
+    for (long long r = 0; r < n; ++r) {
+        unsigned long long s = seed * 0x2545f4914f6cdd1dull + (unsigned long long)r;
+        if (band) {
+            // k sorted columns without replacement from [lo, hi]: stratified, one per stratum, then clipped windows shift inwards
+            long long lo = r - w, hi = r + w;
+            if (lo < 0) { hi = std::min(n - 1, hi - lo); lo = 0; }
+            if (hi > n - 1) { lo = std::max(0ll, lo - (hi - (n - 1))); hi = n - 1; }
+            const long long span = hi - lo + 1;
+            for (long long i = 0; i < k; ++i) {
+                const long long a = lo + span * i / k, b = lo + span * (i + 1) / k;      // stratum [a, b), b > a since span >= k
+                cols[size_t(i)] = a + (long long)(mix(s) % (unsigned long long)(b - a));
+            }
+        } else {
+            for (long long i = 0; i < k; ++i) cols[size_t(i)] = (long long)(mix(s) % (unsigned long long)n);   // (file order: unsorted, duplicates kept)
+        }
+        for (long long i = 0; i < k; ++i) {
+            csr.column_indices[size_t(r * k + i)] = index_t(cols[size_t(i)]);
+            csr.nonzero_values[size_t(r * k + i)] = value_t(double(mix(s) >> 11) * (2.0 / 9007199254740992.0) - 1.0);
+        }
+    }
+    return csr;
+}
 
 template <typename index_t, typename offset_t, typename value_t>
 static int run(const char* path, const std::vector<std::string>& kinds, const Options& opt) {
-    csr_t<index_t, offset_t, value_t> csr = ToCsr(LoadCoo<index_t, offset_t, value_t>(path));
+    const bool synthetic = std::strncmp(path, "synthetic:", 10) == 0;
+    csr_t<index_t, offset_t, value_t> csr = synthetic ? make_synthetic<index_t, offset_t, value_t>(path + 10, opt.seed)
+                                                      : ToCsr(LoadCoo<index_t, offset_t, value_t>(path));
     const index_t n_rows = csr.number_of_rows, n_cols = csr.number_of_columns;
     const offset_t nnz = csr.number_of_nonzeros;
-    std::cout << "Dataset: " << std::filesystem::path(path).filename().string() << std::endl
+    std::cout << "Dataset: " << (synthetic ? std::string(path) + " seed=" + std::to_string(opt.seed) : std::filesystem::path(path).filename().string()) << std::endl
               << "\tn_rows: " << n_rows << "  n_cols: " << n_cols << "  nnz: " << nnz << std::endl;
 
     std::vector<value_t> vec_x(size_t(n_cols), value_t(1));
@@ -125,8 +202,14 @@ static int run(const char* path, const std::vector<std::string>& kinds, const Op
 int main(int argc, char** argv) {
     std::vector<std::string> kinds;
     Options opt;
-    std::string dtype = "f32", offset = "32";
-    for (int i = 2; i < argc; ++i) {
+    std::string dtype = "f32", offset = "32", dataset = argc > 1 ? argv[1] : "";
+    int first = 2;
+    if (dataset == "--synthetic") {                       // `--synthetic <spec>` in the file's place
+        if (argc < 3) { std::cerr << "--synthetic needs a spec (band:n=..,k=..,w=.. | rand:n=..,k=..)" << std::endl; std::exit(1); }
+        dataset = std::string("synthetic:") + argv[2];
+        first = 3;
+    }
+    for (int i = first; i < argc; ++i) {
         const std::string a = argv[i];
         auto value = [&](const char* name) -> std::string {
             if (i + 1 >= argc) { std::cerr << name << " needs a value" << std::endl; std::exit(1); }
@@ -139,6 +222,7 @@ int main(int argc, char** argv) {
         else if (a == "--sub-blocks") mi355_host::dist_sub_blocks() = std::max(1, std::atoi(value("--sub-blocks").c_str()));
         else if (a == "--no-poison") opt.poison = false;
         else if (a == "--unit-us") opt.unit_us = true;
+        else if (a == "--seed") opt.seed = std::strtoull(value("--seed").c_str(), nullptr, 10);
         else kinds.push_back(a);
     }
     if (argc < 3 || kinds.empty()) {
@@ -146,8 +230,8 @@ int main(int argc, char** argv) {
         std::exit(1);
     }
     const bool f64 = dtype == "f64", o64 = offset == "64";
-    if (!f64 && !o64) return run<int, int, float>(argv[1], kinds, opt);
-    if (f64 && !o64) return run<int, int, double>(argv[1], kinds, opt);
-    if (!f64 && o64) return run<int, long long, float>(argv[1], kinds, opt);
-    return run<int, long long, double>(argv[1], kinds, opt);
+    if (!f64 && !o64) return run<int, int, float>(dataset.c_str(), kinds, opt);
+    if (f64 && !o64) return run<int, int, double>(dataset.c_str(), kinds, opt);
+    if (!f64 && o64) return run<int, long long, float>(dataset.c_str(), kinds, opt);
+    return run<int, long long, double>(dataset.c_str(), kinds, opt);
 }

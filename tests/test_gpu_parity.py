@@ -586,6 +586,50 @@ def test_one_shot_calls_keep_their_plan_and_survive_a_rewritten_matrix(sp, oracl
     sp.capi.cache_release()
 
 
+@pytest.mark.parametrize("kind", KINDS)
+def test_kept_one_shot_plan_meets_a_row_beyond_every_giant_threshold(sp, oracle, kind):
+    """The hole the plan cache leaves open by design: a plan kept for a matrix WITHOUT giant rows meets, at the same
+    addresses and sizes, a matrix with a row of 1.5 M nonzeros — far beyond the 64 K at which any fresh plan would cut
+    it into slices for several workgroups.  The kept plan has no slice list: the row is summed by the one workgroup
+    that owns it (long-row / whole-workgroup passes of the chunk body, the merge kind's tiles as ever).  Slow, and
+    right: that is the documented trade ("What the one-shot entry points retain")."""
+    rng = np.random.RandomState(321)
+    n, k = 100_000, 32
+    nnz = n * k
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    Ap1 = (np.arange(n + 1, dtype=np.int64) * k).astype(np.int32)
+    Aj1 = np.clip(np.repeat(np.arange(n), k) + rng.randint(-500, 501, size=nnz), 0, n - 1).astype(np.int32)
+    hub = 1_500_000
+    lens = rng.multinomial(nnz - hub, np.ones(n - 1) / (n - 1))
+    lens = np.insert(lens, 31_337, hub)
+    Ap2 = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=Ap2[1:])
+    Ap2 = Ap2.astype(np.int32)
+    Aj2 = rng.randint(0, n, size=nnz).astype(np.int32)
+    Ax = (rng.rand(nnz) * 2 - 1).astype(np.float32)
+    x = (rng.rand(n) * 2 - 1).astype(np.float32)
+    dAp, dAj, dAx, dx = d(Ap1), d(Aj1), d(Ax), d(x)
+    sp.capi.cache_release()
+    y = torch.full((n,), float("nan"), device=DEV)
+    sp.spmv(kind, n, n, nnz, dAp, dAj, dAx, dx, y)       # the plan of the banded matrix is kept
+    assert_parity(oracle, Ap1, Aj1, Ax, x, y.cpu().numpy())
+    dAp.copy_(d(Ap2))
+    dAj.copy_(d(Aj2))
+    y.fill_(float("nan"))
+    sp.spmv(kind, n, n, nnz, dAp, dAj, dAx, dx, y)       # ... and meets the hub row
+    assert_parity(oracle, Ap2, Aj2, Ax, x, y.cpu().numpy())
+    # a fresh plan for the same arrays does cut the row into slices (more kernels per execute) and agrees
+    sp.capi.cache_release()
+    p = sp.Plan(kind, n, n, nnz, dAp, dAj, torch.float32)
+    if kind != "merge":
+        assert p.info()["n_kernels"] == 3
+    y2 = torch.full((n,), float("nan"), device=DEV)
+    p.execute(dAx, dx, y2)
+    torch.cuda.synchronize()
+    p.destroy()
+    assert_parity(oracle, Ap2, Aj2, Ax, x, y2.cpu().numpy())
+
+
 def test_one_shot_calls_from_several_threads_share_nothing(sp, oracle):
     """Four host threads call the one-shot entry point on the SAME matrix at once, each on its own stream with its own y:
     a kept plan is taken OUT of the cache by its user (its scratch serves one execute at a time), so a second thread

@@ -124,3 +124,36 @@ def test_vendor_comparison_kinds_in_the_harness(exe):
         assert float(m.group(2)) < 1e-3
     r = run(exe, path, "rocsparse", "--offset", "64")
     assert r.returncode == 1 and "32-bit row offsets" in r.stderr
+
+
+def test_synthetic_spec_errors_without_a_gpu(exe):
+    """--synthetic / synthetic:<spec> in the file's place (SURVEY §5 "config / flags"): a bad spec is refused before
+    anything touches the device."""
+    r = run(exe, "--synthetic")
+    assert r.returncode == 1 and "--synthetic needs a spec" in r.stderr
+    r = run(exe, "synthetic:blob:n=10", "hip_vector")
+    assert r.returncode == 1 and "family is band or rand" in r.stderr
+    r = run(exe, "--synthetic", "band:n=100,k=300,w=10", "hip_vector")
+    assert r.returncode == 1 and "synthetic spec: need" in r.stderr
+
+
+@pytest.mark.gpu
+def test_harness_on_seeded_synthetic_matrices(exe):
+    """The harness on a generated matrix instead of a file: the delta table against the serial CPU loop, the same
+    dataset under the same seed, another one under another seed."""
+    outs = []
+    for args in (["--synthetic", "band:n=200000,k=32,w=4096", "hip_vector", "hip_merge", "hip_light", "--iters", "10"],
+                 ["synthetic:band:n=200000,k=32,w=4096", "hip_vector", "hip_merge", "hip_light", "--iters", "10", "--seed", "1"],
+                 ["synthetic:band:n=200000,k=32,w=4096", "hip_vector", "hip_merge", "hip_light", "--iters", "10", "--seed", "9"],
+                 ["--synthetic", "rand:n=100000,k=16", "hip_merge", "hip_dist_vector", "--iters", "5", "--dtype", "f64", "--offset", "64"]):
+        r = run(exe, *args)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout)
+        n, k = (200000, 32) if "band" in " ".join(args) else (100000, 16)
+        assert "n_rows: %d  n_cols: %d  nnz: %d" % (n, n, n * k) in r.stdout
+        for m in re.finditer(r"^\[(\S+) *\] sum: +([0-9.eE+-]+|nan)  avg: +([0-9.eE+-]+|nan)$", r.stdout, re.M):
+            assert float(m.group(3)) < 1e-4, r.stdout             # |y - y_cpu| per row: rounding only
+        assert len(re.findall(r"^\[\S+ *\] sum:", r.stdout, re.M)) == len([a for a in args if a.startswith("hip_")])
+    delta = lambda o: re.findall(r"sum: +(\S+)", o)
+    assert delta(outs[0]) == delta(outs[1])                          # default seed is 1
+    assert delta(outs[0]) != delta(outs[2])
