@@ -2,7 +2,7 @@
 """vector / light on fixed row lengths 4 .. 72 (2^27 nonzeros, band +-4096): a scan for cliffs of the plan rules."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 sp = g.load_package()

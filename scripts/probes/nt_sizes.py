@@ -4,7 +4,7 @@ matrices of growing size, every kind; run once per library (MI355_SPMV_LIB = lib
 -DMI355_STREAM_PLAIN), merge also with the in-kernel search forced off / on."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 sp = g.load_package()

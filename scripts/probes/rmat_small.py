@@ -2,7 +2,7 @@
 """Small power-law matrices (R-MAT 16 .. 20): vector / light under a few knobs against merge — why is the row-based kind 2x behind?"""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 sp = g.load_package()

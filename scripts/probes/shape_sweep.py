@@ -3,7 +3,7 @@
 kind — a scan for cliffs in the plan heuristics (window fits / does not fit, lanes per row, chunk sizes)."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 sp = g.load_package()

@@ -5,7 +5,7 @@ plan's (the parity tests proper, against the oracle, are tests/test_gpu_parity.p
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 sp = g.load_package()

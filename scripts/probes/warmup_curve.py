@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How long does a kernel take to reach its steady time?  Successive windows of executes from a fresh plan, per workload."""
 import os, sys, time, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 sp = g.load_package()
