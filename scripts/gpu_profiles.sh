@@ -20,7 +20,7 @@ pmc() {
 trace s32_vector --kind vector
 trace s32_light --kind light
 trace s32_merge --kind merge
-trace s32_merge_walk --kind merge --steps 60
+MI355_MERGE_ROWS=0 trace s32_merge_walk --kind merge --steps 60
 trace c2_vector --workload c2-cant --kind vector --steps 400 --warmup 200
 trace c2_light --workload c2-cant --kind light --steps 400 --warmup 200
 trace c2_merge --workload c2-cant --kind merge --steps 400 --warmup 200
