@@ -60,7 +60,7 @@ python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --steps 20 --warmup 5 > $O/bench_driver_style.json 2> $O/bench_driver_style.err
 python3 bench.py --cold --no-cpu-baseline --workload c2-cant --kind vector --steps 200 > $O/bench_c2_cold.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --workload c2-cant --kind vector --steps 2000 --warmup 200 > $O/bench_c2_warm.json 2>/dev/null
-python3 scripts/probes/vendor_cmp.py > $O/vendor_rocsparse_same_box.txt 2> $O/vendor.err || tail -3 $O/vendor.err
+python3 scripts/probes/vendor_cmp.py s32-band c2-cant c3-webgoogle c4-nlpkkt c5-rmat24 s32-rand --no-torch-sparse > $O/vendor_rocsparse_same_box.txt 2> $O/vendor.err || tail -3 $O/vendor.err
 # keep the small per-run stats tables, drop the bulky traces
 for d in $O/trace_*/; do f=$(find $d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/$(basename $d)_kernel_stats.csv; done
 find $O -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +

@@ -12,7 +12,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 KEYS = ("csr_vector_window_kernel", "csr_vector_sweep_kernel", "csr_vector_kernel", "light_rows_window_kernel",
-        "light_rows_kernel", "merge_rows_kernel", "merge_tile_kernel", "merge_search_kernel", "merge_fixup_kernel",
+        "light_rows_sweep_kernel", "light_rows_kernel", "merge_rows_kernel", "merge_tile_kernel", "merge_search_kernel", "merge_fixup_kernel",
         "merge_small_kernel", "giant_")
 
 

@@ -500,6 +500,7 @@ __device__ __forceinline__ void chunk_rows(int64_t chunk_begin, int64_t chunk_en
     // (measured with 4 / 3 sets for the fp32 / fp64 R = 2 bodies: cant stand-in 11.3 -> 12.6 us, C4 stand-in 541 -> 602 us:
     // the extra sets cost more occupancy than the deeper prefetch buys; two everywhere)
     // (round 3, C4 stand-in with 3 sets and 168 registers, which its LDS-bound three workgroups per CU allow: 585 -> 602 us)
+    // (round 3 again, on the rewritten body: 3 / 4 sets on the cant stand-in 10.8 -> 13.9 / 12.2 us at 93 / 107 registers)
     constexpr int DEPTH = 2;
     Group G[DEPTH];
 #pragma unroll
