@@ -137,6 +137,7 @@ struct Plan {
     bool window_from_band;      // place the window from band_lo/band_hi instead of sampling per chunk
     int mr_block = 256;         // MERGE, row-parallel runs: workgroup size (512: the band needs ~78 KB of LDS) and rows per piece of a run
     int mr_piece_rows = 1984;
+    int mr_sweep_lanes = 0;     // MERGE, row-parallel runs on a band wider than any window: lanes per row of the sweeping body (0 = not swept)
     bool sweep = false;         // VECTOR: the band is wider than any window — one group of rows per chunk, the window sweeps the band (chunk_rows_sweep)
     // multi-band plan: up to 4 bands of (column - row) found by clustering the probe's samples
     int n_seg;

@@ -482,7 +482,10 @@ constexpr int kMergeRowsCap = 1984;    // rows per piece: bounds + results fit 1
 // SEARCH: the workgroup finds its two diagonals itself (grids of a few rounds); else run_row / run_nnz hold the run
 // boundaries, found by the search kernel on n_super + 1 diagonals (every workgroup of a big grid would otherwise pay
 // the chain of dependent loads at its start).
-template <int BLOCK, int R, bool WINDOW, bool SEARCH, typename off_t, typename val_t>
+// TS > 0: the band is wider than any window (plan: shape_merge, mr_sweep_lanes) — a piece is then ONE group of rows of the
+// 1 024-thread workgroup, TS lanes per row and R rows per vector held in registers, and the window sweeps the band
+// (xwindow.hpp, chunk_rows_sweep: the CSR-vector kind's body for such bands; plain gathers ran the run at 1.6 TB/s).
+template <int BLOCK, int R, bool WINDOW, bool SEARCH, typename off_t, typename val_t, int TS = 0>
 __global__ __launch_bounds__(BLOCK, (BLOCK >= kWideBlock ? 4 : 3)) void merge_rows_kernel(
     int32_t n_rows, int32_t n_cols, int64_t nnz_begin, int64_t nnz, const off_t* __restrict__ Ap,
     const int32_t* __restrict__ Aj_arg, const val_t* __restrict__ Ax_arg, const val_t* __restrict__ x_arg,
@@ -554,6 +557,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= kWideBlock ? 4 : 3)) void merge_ro
         scr.store_rows = int(min(pe, n_store_all) - pb);              // the open row's partial stays in s_y
         __syncthreads();
         const int64_t rb = row_lo + pb, re = row_lo + pe;
+        if constexpr (TS > 0) {
+            chunk_rows_sweep<BLOCK, TS, R, val_t>(rb, re, nnz_c, Aj_c, Ax_c, x, y, n_cols, window_cap, hint, scr);
+            __syncthreads();
+            if (pe == n_all && n_all > n_store_all) carry = uniform_val(scr.s_y[rows - 1]);
+            __syncthreads();
+            continue;
+        }
         auto first_last = [&](int64_t r, int& fc, int& lc) {
             const int32_t s = scr.s_b[r - rb], e = scr.s_b[r - rb + 1];
             if (e <= s) return false;
@@ -703,6 +713,41 @@ void shape_merge(Plan& p) {
             p = saved;
         }
     }
+    // Still no window: the band is wider than one CU's LDS.  The CSR-vector kind sweeps such a band with the window
+    // (analyze.hip, shape_sweep); a run here does the same — a piece = one group of rows of a 1 024-thread workgroup held in
+    // registers, 4 T nonzeros per row in one step — under the same rule: the staged bytes of a piece stay below half the
+    // line fills its nonzeros would cost as plain gathers.  Rows of up to 8 nonzeros (T = 2) keep the gathers.
+    p.mr_sweep_lanes = 0;
+    if (p.merge_rows && p.window_elems == 0 && p.probe_ok && p.knob.sweep != 0 && p.knob.window < 0 && p.knob.merge_tps <= 0 &&
+        p.knob.merge_wide_window != 0 && p.probe_len_max > 8 && p.probe_len_max <= 128) {
+        const int64_t vb = p.val_type == MI355_VAL_F64 ? 8 : 4;
+        const int64_t band = p.band_hi - p.band_lo + 1;
+        const int64_t mean1 = 1 + (p.n_rows > 0 ? (p.nnz - p.nnz_begin) / p.n_rows : 0);
+        int t = 4;
+        while (t < 32 && 4 * t < p.probe_len_max) t *= 2;
+        const int64_t piece = int64_t(kHugeBlock / t) * sweep_rows_for(p.val_type, t);
+        const int64_t fixed = int64_t(chunk_lds_bytes(0, int(piece), size_t(vb)));
+        const int64_t cap = ((155 * 1024 - fixed) / vb) & ~int64_t(3);
+        const int64_t span = band + piece + 8;
+        const int64_t passes = cap > 0 ? (span + cap - 1) / cap : 0;
+        int64_t t2 = piece * mean1 / p.tile_items;
+        if (t2 > kMergeSuperItems / p.tile_items) t2 = kMergeSuperItems / p.tile_items;
+        if (t2 < 1) t2 = 1;
+        const int64_t n_super = (p.n_tiles + t2 - 1) / t2;
+        const bool pays = span * vb <= 64 * (mean1 - 1) * piece;
+        if (band > 0 && passes >= 1 && passes <= 16 && n_super >= int64_t(kCus) * 2 && (pays || p.knob.sweep == 1)) {
+            p.tiles_per_super = t2;
+            p.n_super = n_super;
+            p.grid_blocks = n_super;
+            p.mr_block = kHugeBlock;
+            p.mr_piece_rows = int(piece);
+            p.mr_sweep_lanes = t;
+            p.window_bytes = int(cap * vb);
+            p.window_elems = int(cap);
+            p.window_from_band = true;
+            p.n_seg = 0;
+        }
+    }
     if (p.merge_rows) {
         p.n_kernels = (p.n_super > 1 ? 2 : 1) + (merge_search_in_kernel(p) ? 0 : 1);
         snprintf(p.main_kernel, sizeof(p.main_kernel), "merge_rows_kernel");
@@ -768,7 +813,31 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
                            p.carry_row, static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super,    \
                            capw, hint_r, (val_t)p.alpha, (val_t)p.beta, (int32_t)p.mr_piece_rows);                  \
     } while (0)
-            if (p.mr_block == kHugeBlock && capw > 0) {       // (the wide run kernels exist around ONE window of x)
+            if (p.mr_sweep_lanes > 0 && capw > 0) {           // the window sweeps the band: one group of rows per piece
+                constexpr int RS = sizeof(val_t) == 4 ? 8 : kSweepRows;
+                const BandHint hint_s{p.band_lo, p.band_hi, true};
+                if (p.mr_piece_rows != (kHugeBlock / p.mr_sweep_lanes) * RS) {
+                    set_error("merge: sweep plan with %d rows per piece at %d lanes per row", p.mr_piece_rows, p.mr_sweep_lanes);
+                    return MI355_SPMV_EINVAL;
+                }
+#define MI355_MERGE_SWEEP_LAUNCH(TS_, SEARCH_)                                                                     \
+    do {                                                                                                           \
+        if (const int st = allow_dynamic_lds((const void*)merge_rows_kernel<kHugeBlock, RS, true, SEARCH_, off_t, val_t, TS_>, lds + 1024)) return st; \
+        hipLaunchKernelGGL((merge_rows_kernel<kHugeBlock, RS, true, SEARCH_, off_t, val_t, TS_>), grid_r, dim3(kHugeBlock), lds, s, p.n_rows, \
+                           p.n_cols, p.nnz_begin, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_items, p.tile_row, p.tile_nnz,   \
+                           p.carry_row, static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super,    \
+                           capw, hint_s, (val_t)p.alpha, (val_t)p.beta, (int32_t)p.mr_piece_rows);                  \
+    } while (0)
+                switch (p.mr_sweep_lanes) {
+                    case 4:  if (in_kernel) MI355_MERGE_SWEEP_LAUNCH(4, true); else MI355_MERGE_SWEEP_LAUNCH(4, false); break;
+                    case 8:  if (in_kernel) MI355_MERGE_SWEEP_LAUNCH(8, true); else MI355_MERGE_SWEEP_LAUNCH(8, false); break;
+                    case 16: if (in_kernel) MI355_MERGE_SWEEP_LAUNCH(16, true); else MI355_MERGE_SWEEP_LAUNCH(16, false); break;
+                    case 32: if (in_kernel) MI355_MERGE_SWEEP_LAUNCH(32, true); else MI355_MERGE_SWEEP_LAUNCH(32, false); break;
+                    default: set_error("merge: bad sweep width %d", p.mr_sweep_lanes); return MI355_SPMV_EINVAL;
+                }
+#undef MI355_MERGE_SWEEP_LAUNCH
+            }
+            else if (p.mr_block == kHugeBlock && capw > 0) {       // (the wide run kernels exist around ONE window of x)
                 if (in_kernel) MI355_MERGE_ROWS_LAUNCH(kHugeBlock, true, true); else MI355_MERGE_ROWS_LAUNCH(kHugeBlock, true, false);
             }
             else if (p.mr_block == kWideBlock && capw > 0) {

@@ -536,6 +536,58 @@ def test_band_wider_than_any_window_is_swept(sp, oracle, off, val, kind):
         assert torch.equal(y.view(torch.int32 if val == "f32" else torch.int64), y_blocks.view(torch.int32 if val == "f32" else torch.int64))
 
 
+@pytest.mark.parametrize("off,val", [("i32", "f32"), ("i64", "f64")])
+def test_merge_runs_sweep_a_band_wider_than_any_window(sp, oracle, off, val):
+    """The merge kind on the same shape: its row-parallel runs take the sweeping body too (merge_rows_kernel with 1 024
+    threads, a piece = one group of rows held in registers; plain gathers ran such runs at 1.6 TB/s).  Regular rows only
+    (the probe must see rows that all but fill one step), plus what the probe's sample cannot see: a few rows of 200
+    nonzeros, columns far outside the band, an empty row; 31 per row so that rows straddle the 16-byte groups and the run
+    boundaries fall inside rows (carries through the fix-up kernel)."""
+    rng = np.random.default_rng(37)
+    n, per_row = 600_003, 31
+    hw = 40_000 if val == "f32" else 20_000
+    lens = np.full(n, per_row, dtype=np.int64)
+    probed = set(((n - 1) * np.arange(256)) // 255)
+    special = [r for r in (5, 1001, 150_001, n - 2) if r not in probed]
+    lens[special] = 200
+    lens[[r for r in (7, 333_333) if r not in probed]] = 0
+    Ap = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=Ap[1:])
+    nnz = int(Ap[-1])
+    rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+    lo = np.clip(rows - hw, 0, n - 1)
+    hi = np.clip(rows + hw, 0, n - 1)
+    cols = lo + (rng.random(nnz) * (hi - lo + 1)).astype(np.int64)
+    for r in [r for r in (9, 2000, 250_000) if r not in probed]:
+        cols[Ap[r]] = 0 if r > n // 2 else n - 1
+        cols[Ap[r + 1] - 1] = n - 1 if r > n // 2 else 0
+    order = np.lexsort((cols, rows))
+    Aj = cols[order].astype(np.int32)
+    Ax = (rng.random(nnz) - 0.5).astype(NP[val])
+    x = seeded_x(n, NP[val])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    dAp, dAj, dAx, dx = d(Ap.astype(NP[off])), d(Aj), d(Ax), d(x)
+    p = sp.Plan("merge", n, n, nnz, dAp, dAj, dAx.dtype)
+    info = p.info()
+    forced = any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB")
+    if not forced:
+        assert info["main_kernel"] == "merge_rows_kernel" and info["block_threads"] == 1024 and info["window_elems"] > 30_000 // (2 if val == "f64" else 1), info
+    for _ in range(2):                                   # twice: the run boundaries / carries are rewritten by every execute
+        y = torch.full((n,), float("nan"), dtype=dAx.dtype, device=DEV)
+        p.execute(dAx, dx, y)
+        torch.cuda.synchronize()
+        assert_parity(oracle, Ap.astype(NP[off]), Aj, Ax, x, y.cpu().numpy())
+    y_old = torch.from_numpy(seeded_x(n, NP[val])).to(DEV) * 0.5
+    y_ab = y_old.clone()
+    p.set_alpha_beta(-0.75, 3.0)
+    p.execute(dAx, dx, y_ab)
+    torch.cuda.synchronize()
+    p.destroy()
+    want_ab = -0.75 * y.double() + 3.0 * y_old.double()
+    eps = 2.0 ** -23 if val == "f32" else 2.0 ** -52
+    assert bool(((y_ab.double() - want_ab).abs() <= 4 * eps * (0.75 * y.double().abs() + 3.0 * y_old.double().abs()) + 1e-300).all())
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_one_shot_calls_keep_their_plan_and_survive_a_rewritten_matrix(sp, oracle, kind):
     """The one-shot entry points find the plan of their previous call again by the pointers and sizes of Ap / Aj (the
