@@ -774,7 +774,7 @@ bool shape_sweep(Plan& p) {
     while (t < kWave && 4 * t < p.probe_len_max) t *= 2;
     const int64_t rows = int64_t(kHugeBlock / t) * sweep_rows_for(p.val_type, t);
     const int64_t fixed = int64_t(chunk_lds_bytes(0, int(rows), size_t(val_bytes)));
-    const int64_t cap = ((155 * 1024 - fixed) / val_bytes) & ~int64_t(3);
+    const int64_t cap = sweep_window_cap(val_bytes, fixed);
     const int64_t span = band + rows + 8;
     const int64_t passes = cap > 0 ? (span + cap - 1) / cap : 0;
     const int64_t mean = p.n_rows > 0 ? (p.nnz - p.nnz_begin) / p.n_rows : 0;

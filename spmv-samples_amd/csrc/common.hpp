@@ -30,6 +30,14 @@ constexpr int kSweepRows = 4;        // rows a vector of the sweep kernel holds 
 // same window passes then serve twice the nonzeros — staging the band, not the Aj / Ax stream, is what a swept chunk
 // waits for (band of 65 537 columns, 2^22 rows x 32: 371 -> 321 us; 131 073 columns: 508 -> 411).  fp64 keeps 4: eight
 // rows of doubles do not fit the 128 registers a 1 024-thread workgroup has per lane.
+// Window of x of a sweeping 1 024-thread workgroup, in elements: what is left of ~155 KB of the CU's LDS next to the
+// chunk's own arrays (`fixed_bytes`), in whole ROUNDS of the workgroup's 16-byte groups (16 KB) — the window is staged by
+// global_load_lds, whose every wave-instruction fills 64 x 16 bytes of LDS (xwindow.hpp, chunk_rows_sweep).
+inline int64_t sweep_window_cap(int64_t val_bytes, int64_t fixed_bytes) {
+    const int64_t round = int64_t(kHugeBlock) * 16;
+    const int64_t rounds = (155 * 1024 - fixed_bytes) / round;
+    return rounds > 0 ? rounds * round / val_bytes : 0;
+}
 inline int sweep_rows_for(int val_type, int lanes_per_row) {
     return (val_type == MI355_VAL_F32 && (kHugeBlock / lanes_per_row) * 8 <= 2048) ? 8 : kSweepRows;
 }

@@ -486,7 +486,7 @@ static int launch_light_sweep(const Plan& p, const ApView Ap, const val_t* Ax, c
     const int held = int(p.rows_per_chunk / vectors);
     constexpr bool kHasEight = sizeof(val_t) == 4;
     if (p.rows_per_chunk != vectors * held || !(held == kSweepRows || (kHasEight && held == 8 && p.lanes_per_row >= 4)) ||
-        p.rows_cap < p.rows_per_chunk) {
+        p.rows_cap < p.rows_per_chunk || p.window_elems < int(kHugeBlock * 16 / sizeof(val_t))) {
         set_error("light_rows: sweep plan with %lld rows per chunk at %d lanes per row", (long long)p.rows_per_chunk, p.lanes_per_row);
         return MI355_SPMV_EINVAL;
     }

@@ -727,7 +727,7 @@ void shape_merge(Plan& p) {
         while (t < 32 && 4 * t < p.probe_len_max) t *= 2;
         const int64_t piece = int64_t(kHugeBlock / t) * sweep_rows_for(p.val_type, t);
         const int64_t fixed = int64_t(chunk_lds_bytes(0, int(piece), size_t(vb)));
-        const int64_t cap = ((155 * 1024 - fixed) / vb) & ~int64_t(3);
+        const int64_t cap = sweep_window_cap(vb, fixed);
         const int64_t span = band + piece + 8;
         const int64_t passes = cap > 0 ? (span + cap - 1) / cap : 0;
         int64_t t2 = piece * mean1 / p.tile_items;
@@ -816,7 +816,7 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
             if (p.mr_sweep_lanes > 0 && capw > 0) {           // the window sweeps the band: one group of rows per piece
                 constexpr int RS = sizeof(val_t) == 4 ? 8 : kSweepRows;
                 const BandHint hint_s{p.band_lo, p.band_hi, true};
-                if (p.mr_piece_rows != (kHugeBlock / p.mr_sweep_lanes) * RS) {
+                if (p.mr_piece_rows != (kHugeBlock / p.mr_sweep_lanes) * RS || capw < int32_t(kHugeBlock * 16 / sizeof(val_t))) {
                     set_error("merge: sweep plan with %d rows per piece at %d lanes per row", p.mr_piece_rows, p.mr_sweep_lanes);
                     return MI355_SPMV_EINVAL;
                 }

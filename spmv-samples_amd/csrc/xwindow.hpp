@@ -800,10 +800,6 @@ __device__ __forceinline__ void chunk_rows_any(int64_t chunk_begin, int64_t chun
     }
 }
 
-// 16-byte loads a thread of the sweep (chunk_rows_sweep) keeps in flight while a window is staged: a window of
-// ~9 600 groups is one batch in fp32, two in fp64 (whose body holds 32 more registers of Ax).
-__host__ __device__ constexpr int sweep_loads(size_t val_bytes, int rows_held = 4) { return rows_held > 4 ? 4 : (val_bytes == 4 ? 10 : 5); }
-
 // A band too wide for ANY window (more columns than a CU's LDS holds): the window SWEEPS the band.
 // The plain gather is bound by line fills — every lane of a gather instruction pulls its own 128-byte line
 // into the CU for 4 useful bytes (measured: ~96 cycles per 64-lane gather at a 131 K-column band) — while a
@@ -825,10 +821,8 @@ __device__ __forceinline__ void chunk_rows_sweep(int64_t chunk_begin, int64_t ch
                                                  const ChunkScratch<val_t>& scr) {
     using v4 = typename Vec4<val_t>::type;
     using off_t = int32_t;
-    using v16 = typename std::conditional<sizeof(val_t) == 4, float4v, double __attribute__((ext_vector_type(2)))>::type;
     constexpr int PER16 = 16 / int(sizeof(val_t));
     constexpr int VW = kWave / T;
-    constexpr int SWEEP_LOADS = sweep_loads(sizeof(val_t), R);
     // (opaque copy of the thread index: inside the kernel's loop over chunks the optimiser otherwise hoists every
     // per-thread value below out of the loop, keeps them all live across the chunk and spills)
     int tid = threadIdx.x;
@@ -872,34 +866,47 @@ __device__ __forceinline__ void chunk_rows_sweep(int64_t chunk_begin, int64_t ch
     int64_t l = chunk_begin + hint.lo, h = chunk_end - 1 + hint.hi;
     l = l < 0 ? 0 : l;
     h = h >= n_cols ? int64_t(n_cols) - 1 : h;
-    const int c_lo = int(l) & ~(PER16 - 1), c_hi = int(h);    // (h < l: an empty sweep, everything falls to the gathers)
-    // Staging: SWEEP_LOADS 16-byte loads in flight per thread, straight-line (a conditional load makes hipcc wait for
-    // every load before the next, s_waitcnt vmcnt(0) at each branch): a group index past the window's end wraps
-    // to its first groups, which are loaded and stored a second time (same bytes, DISTINCT LDS addresses: clamping
-    // them all to the last group makes every lane of a wave store to one address).
-    // (Tried and dropped: the loads of window p + 1 issued before window p is consumed and held in registers
-    // meanwhile — 203 vs 190 us at two passes, 432 vs 370 at seven; a persistent workgroup per CU walking its share
-    // of the chunks — 194 vs 187, 438 vs 358; touching the Aj / Ax lines of the chunk one round of the chip ahead
-    // while sweeping, so that HBM does not idle — 414 vs 370 us on 2^22 rows at two passes, 570 vs 508 at four.)
+    // (the last n_cols % PER16 columns of x are not part of any staged window — a window is whole 16-byte groups,
+    // written by LDS-DMA — and fall to the gathers below with everything else outside the swept span; h < l: an empty
+    // sweep, everything falls to the gathers)
+    const int whole_end = (n_cols & ~(PER16 - 1)) - 1;
+    const int c_lo = int(l) & ~(PER16 - 1), c_hi = int(h) < whole_end ? int(h) : whole_end;
+    // (Tried and dropped, rounds 2-3: staging through registers — 10 loads per thread and batch, 4 for the eight-row
+    // body: a 150 KB window was three dependent round trips; the loads of window p + 1 held in registers across the
+    // consume of window p — 203 vs 190 us at two passes, 432 vs 370 at seven; a persistent workgroup per CU walking its
+    // share of the chunks — 194 vs 187, 438 vs 358; touching the Aj / Ax lines of the chunk one round of the chip ahead
+    // while sweeping — 414 vs 370 us on 2^22 rows at two passes, 570 vs 508 at four.)
+    cap = (cap / (BLOCK * PER16)) * (BLOCK * PER16);           // whole rounds of the workgroup's 16-byte groups (the launchers check cap >= one round)
     for (int w0 = c_lo; w0 <= c_hi; w0 += cap) {               // uniform over the workgroup; cap is a multiple of PER16
         const int len = min(cap, c_hi + 1 - w0);
         int full = (min(w0 + len, n_cols & ~(PER16 - 1)) - w0) / PER16;   // whole 16-byte groups of the window inside x
         full = full > 0 ? full : 0;
         if (w0 != c_lo) __syncthreads();                       // the previous window is still being read
-        for (int g0 = 0; g0 < full; g0 += SWEEP_LOADS * BLOCK) {   // uniform; the plan's window: one or two batches
-            v16 t[SWEEP_LOADS];
-            int gi[SWEEP_LOADS];
-#pragma unroll
-            for (int u = 0; u < SWEEP_LOADS; ++u) {
-                int g = g0 + u * BLOCK + tid;
-                g = g < full ? g : g - full;
-                gi[u] = min(g, full - 1);                      // (a window shorter than one batch)
-                t[u] = *reinterpret_cast<const v16*>(x + w0 + gi[u] * PER16);
+        // The window goes from global memory STRAIGHT into LDS (global_load_lds_dwordx4: no destination registers, so
+        // every 16-byte group of the window is in flight at once whatever the chunk holds in registers).  Through
+        // registers the eight-row fp32 body had 4 loads per thread and batch: a window of 150 KB was three DEPENDENT
+        // round trips to L2, and staging — not the Aj / Ax stream, which this structure reads at 7.8 TB/s, nor the
+        // consume — was more than half the kernel (321 us; 144 without the passes; 338 with the passes and half the
+        // consumes).  A wave-instruction writes LDS at a wave-uniform base + 16 bytes x lane, which is the window's
+        // own layout.  cap is a whole number of such rounds of the workgroup (analyze.hip: shape_sweep), so every lane
+        // of every instruction has a slot inside the window's LDS: a group past the window's end re-loads the last
+        // whole group of x into a slot nothing reads.  The instructions count on vmcnt: the wait + the barrier below
+        // order them before every wave's ds_reads.
+        {
+            const int wave_first = (tid & ~(kWave - 1));             // this wave's first thread
+            const int rounds = cap / (BLOCK * PER16);
+            const int last = full > 0 ? full - 1 : 0;
+            for (int u = 0; u < rounds; ++u) {                       // uniform
+                const int g = u * BLOCK + tid;
+                const int gs = g < full ? g : last;
+                const val_t* src = x + w0 + gs * PER16;
+                val_t* dst = scr.s_x + (u * BLOCK + wave_first) * PER16;     // wave-uniform: + lane * 16 bytes by the hardware
+                if (full > 0)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             }
-#pragma unroll
-            for (int u = 0; u < SWEEP_LOADS; ++u) *reinterpret_cast<v16*>(scr.s_x + gi[u] * PER16) = t[u];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        for (int i = full * PER16 + tid; i < len; i += BLOCK) scr.s_x[i] = x[w0 + i];   // (the last columns of x)
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
