@@ -176,3 +176,60 @@ def test_dist_execute_is_capturable_and_cheap_with_one_block(sp):
     p.destroy()
     d.destroy()
     assert torch.equal(y, y1)
+
+
+@pytest.mark.parametrize("kind", ["vector", "light"])
+def test_block_that_ends_inside_the_arrays_last_partial_group(sp, kind):
+    """a block that is not the last one reads the tail of its last row in whole 16-byte groups — but never
+    past the END of the whole arrays.  Here the matrix ends with rows that hold 2 nonzeros in all and nnz % 4 == 1 + 2:
+    the middle block's rounded-up view would reach 1-3 elements past Aj / Ax.  Aj / Ax are allocated EXACTLY (views of a
+    larger buffer poisoned behind the end would show a stray read as NaN / a wild column); results bit for bit the
+    whole plan's."""
+    m0 = sp.synth.banded_fixed(8192, 32, 300, seed=77, device=DEV)
+    probe = sp.Plan(kind, m0.n_rows, m0.n_cols, m0.nnz, m0.Ap, m0.Aj, m0.Ax.dtype)
+    rpc = probe.info()["rows_per_chunk"]
+    probe.destroy()
+    assert rpc > 0 and 8192 % rpc == 0
+    # rows [0, 8192): 32 per row, minus 3 nonzeros of the last one -> A = 8192 * 32 - 3 (A % 4 == 1); then rpc rows with
+    # two 1-nonzero rows among them -> nnz = A + 2
+    n = 8192 + rpc
+    lens = np.full(n, 0, dtype=np.int64)
+    lens[:8192] = 32
+    lens[8191] = 29
+    lens[8192 + 1] = 1
+    lens[n - 1] = 1
+    Ap = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=Ap[1:])
+    nnz = int(Ap[-1])
+    assert (nnz - 2) % 4 == 1
+    rng = np.random.RandomState(5)
+    rows = np.repeat(np.arange(n), lens)
+    Aj = np.clip(rows + rng.randint(-200, 201, size=nnz), 0, n - 1).astype(np.int32)
+    Ax = (rng.rand(nnz) * 2 - 1).astype(np.float32)
+    # exact-size device arrays carved out of poisoned buffers: element nnz .. nnz + 7 hold a wild column / NaN
+    bufj = torch.full((nnz + 8,), 2 ** 30, dtype=torch.int32, device=DEV)
+    bufx = torch.full((nnz + 8,), float("nan"), dtype=torch.float32, device=DEV)
+    bufj[:nnz] = torch.from_numpy(Aj).to(DEV)
+    bufx[:nnz] = torch.from_numpy(Ax).to(DEV)
+    dAj, dAx = bufj[:nnz], bufx[:nnz]
+    dAp = torch.from_numpy(Ap.astype(np.int32)).to(DEV)
+    x = sp.synth.dense_vector(n, torch.float32, 6, DEV)
+    whole = sp.Plan(kind, n, n, nnz, dAp, dAj, torch.float32)
+    y1 = torch.full((n,), float("nan"), device=DEV)
+    whole.execute(dAx, x, y1)
+    torch.cuda.synchronize()
+    shape = whole.shape()
+    assert whole.info()["rows_per_chunk"] == rpc and not whole.info()["balanced_chunks"]
+    whole.destroy()
+    cuts = [0, 4096, 8192, n]
+    y = torch.full((n,), float("nan"), device=DEV)
+    for b in range(3):
+        r0, r1 = cuts[b], cuts[b + 1]
+        a, j, v, lo = sp.dist.block_view(dAp, dAj, dAx, r0, r1)
+        blk = sp.Plan.block(kind, shape, r0, r0 // rpc, (r1 - r0 + rpc - 1) // rpc, int(Ap[r0]), r1 - r0, n, int(a[-1].item()),
+                            a, j, torch.float32)
+        blk.execute(v, x, y[r0:r1])
+        torch.cuda.synchronize()
+        blk.destroy()
+    assert not torch.isnan(y).any()
+    assert torch.equal(y, y1)
