@@ -879,7 +879,9 @@ __device__ __forceinline__ void chunk_rows_sweep(int64_t chunk_begin, int64_t ch
     cap = (cap / (BLOCK * PER16)) * (BLOCK * PER16);           // whole rounds of the workgroup's 16-byte groups (the launchers check cap >= one round)
     for (int w0 = c_lo; w0 <= c_hi; w0 += cap) {               // uniform over the workgroup; cap is a multiple of PER16
         const int len = min(cap, c_hi + 1 - w0);
-        int full = (min(w0 + len, n_cols & ~(PER16 - 1)) - w0) / PER16;   // whole 16-byte groups of the window inside x
+        // 16-byte groups that hold the window's columns: its last, partial group is staged whole (c_hi + 1 need not be a
+        // multiple of PER16; the group lies inside x, c_hi stops at the last whole group of x)
+        int full = (min((w0 + len + PER16 - 1) & ~(PER16 - 1), n_cols & ~(PER16 - 1)) - w0) / PER16;
         full = full > 0 ? full : 0;
         if (w0 != c_lo) __syncthreads();                       // the previous window is still being read
         // The window goes from global memory STRAIGHT into LDS (global_load_lds_dwordx4: no destination registers, so

@@ -583,9 +583,13 @@ def test_merge_runs_sweep_a_band_wider_than_any_window(sp, oracle, off, val):
     p.execute(dAx, dx, y_ab)
     torch.cuda.synchronize()
     p.destroy()
-    want_ab = -0.75 * y.double() + 3.0 * y_old.double()
-    eps = 2.0 ** -23 if val == "f32" else 2.0 ** -52
-    assert bool(((y_ab.double() - want_ab).abs() <= 4 * eps * (0.75 * y.double().abs() + 3.0 * y_old.double().abs()) + 1e-300).all())
+    # bound of test_alpha_beta: (len + 3) eps (|alpha| sum|a x| + |beta y0|) around alpha * y64 + beta * y0 (a row that
+    # straddles runs gets its carry added by the fix-up kernel, so "two roundings of the plain result" does not hold here)
+    y64, yabs = oracle.spmv_ref64(Ap.astype(NP[off]), Aj, Ax, x)
+    y0 = y_old.cpu().numpy().astype(np.float64)
+    eps = 2.0 ** -24 if val == "f32" else 2.0 ** -53
+    bound = (lens + 3) * eps * (0.75 * yabs + 3.0 * np.abs(y0)) + 1e-300
+    assert np.all(np.abs(y_ab.cpu().numpy().astype(np.float64) - (-0.75 * y64 + 3.0 * y0)) <= bound)
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -673,7 +677,7 @@ def test_kept_one_shot_plan_meets_a_row_beyond_every_giant_threshold(sp, oracle,
     # a fresh plan for the same arrays does cut the row into slices (more kernels per execute) and agrees
     sp.capi.cache_release()
     p = sp.Plan(kind, n, n, nnz, dAp, dAj, torch.float32)
-    if kind != "merge":
+    if kind != "merge" and not any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB"):   # (no forced code path)
         assert p.info()["n_kernels"] == 3
     y2 = torch.full((n,), float("nan"), device=DEV)
     p.execute(dAx, dx, y2)
