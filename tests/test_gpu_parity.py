@@ -536,6 +536,26 @@ def test_band_wider_than_any_window_is_swept(sp, oracle, off, val, kind):
         assert torch.equal(y.view(torch.int32 if val == "f32" else torch.int64), y_blocks.view(torch.int32 if val == "f32" else torch.int64))
 
 
+@pytest.mark.parametrize("kind", ["vector", "light"])
+def test_swept_window_that_ends_inside_a_16_byte_group(sp, oracle, kind):
+    """Regression (round 3): the sweep's windows are staged by LDS-DMA in whole 16-byte groups; a window whose last column
+    is not the last of a group (c_hi + 1 - w0 not a multiple of 4) must still hold that group.  The 1 024-thread-plan
+    matrix, forced onto the sweep kernel by forbidding band-placed windows, has such windows in most chunks (found by
+    scripts/gpu_env_matrix.sh, not by the default suite: 26 wrong rows of 1.3 M)."""
+    old = os.environ.get("MI355_SPMV_WINDOW_FROM_BAND")
+    os.environ["MI355_SPMV_WINDOW_FROM_BAND"] = "0"
+    sp.capi.lib().mi355_spmv_knobs_reload()
+    try:
+        for val in ("f32", "f64"):
+            test_band_too_wide_for_two_workgroups_takes_one_of_1024_threads(sp, oracle, val, kind)
+    finally:
+        if old is None:
+            os.environ.pop("MI355_SPMV_WINDOW_FROM_BAND", None)
+        else:
+            os.environ["MI355_SPMV_WINDOW_FROM_BAND"] = old
+        sp.capi.lib().mi355_spmv_knobs_reload()
+
+
 @pytest.mark.parametrize("off,val", [("i32", "f32"), ("i64", "f64")])
 def test_merge_runs_sweep_a_band_wider_than_any_window(sp, oracle, off, val):
     """The merge kind on the same shape: its row-parallel runs take the sweeping body too (merge_rows_kernel with 1 024
