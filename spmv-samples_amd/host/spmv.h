@@ -28,10 +28,27 @@
 #ifdef MI355_WITH_ROCSPARSE
 #define SPMV_KINDS_VENDOR                             \
     X("rocsparse", SpMV_rocsparse)                    \
-    X("rocsparse_stream", SpMV_rocsparse_stream)
+    X("rocsparse_stream", SpMV_rocsparse_stream)      \
+    X("cusparse", SpMV_rocsparse)
 #else
 #define SPMV_KINDS_VENDOR
 #endif
+
+// The reference's own labels (spmv.h:18-27), so a command line or script written for it runs unchanged: each
+// names the MI355X kind that stands in its place (INTEGRATION.md has the table).  The three CUSP variants differ
+// in how a warp reads and reduces a row, the two LightSpMV ones in vector/warp granularity of the row counter,
+// cub_merge / merge in who wrote the merge-path kernel: on gfx950 each family is ONE kernel set whose lanes per
+// row and rows per fetch the analysis picks.  "cusparse" names the vendor column and exists only in a build with
+// -DMI355_WITH_ROCSPARSE (above).
+#define SPMV_KINDS_REFERENCE_LABELS                   \
+    X("cusp", SpMV_hip_vector)                        \
+    X("cusp1", SpMV_hip_vector)                       \
+    X("cusp2", SpMV_hip_vector)                       \
+    X("light_vec", SpMV_hip_light)                    \
+    X("light_warp", SpMV_hip_light)                   \
+    X("cub_merge", SpMV_hip_merge)                    \
+    X("merge", SpMV_hip_merge)                        \
+    X("merge_genl", SpMV_hip_merge_generalized)
 
 /// SPMV kind strings and its function
 #define SPMV_KINDS                                    \
@@ -42,6 +59,7 @@
     X("hip_dist_vector", SpMV_hip_dist_vector)        \
     X("hip_dist_merge", SpMV_hip_dist_merge)          \
     X("hip_dist_light", SpMV_hip_dist_light)          \
+    SPMV_KINDS_REFERENCE_LABELS                       \
     SPMV_KINDS_VENDOR
 
 template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,

@@ -108,6 +108,25 @@ def test_harness_on_a_generated_banded_file(exe, tmp_path):
 
 
 @pytest.mark.gpu
+def test_the_references_own_labels_run_unchanged(exe):
+    """A command line written for the reference (README.md:17-19: `./bin/spmv file.mtx cusp cusp1 ... merge_genl`)
+    runs as it is: every label of spmv.h:18-27 except the vendor column names the MI355X kind standing in its place,
+    and prints under the label it was asked by."""
+    path = os.path.join(GOLD, "c1_1138_bus_standin.mtx")
+    kinds = ["cusp", "cusp1", "cusp2", "light_vec", "light_warp", "cub_merge", "merge", "merge_genl"]
+    r = run(exe, path, *kinds, "--iters", "5")
+    assert r.returncode == 0, r.stderr
+    for k in kinds:
+        m = re.search(r"^\[%-12s\] sum: +([0-9.eE+-]+|nan)  avg: +([0-9.eE+-]+|nan)$" % k, r.stdout, re.M)
+        assert m, r.stdout
+        assert float(m.group(2)) < 1e-3
+        assert re.search(r"^\[%-12s\] total: +([0-9.]+) ms  kernel: +([0-9.]+) ms$" % k, r.stdout, re.M), r.stdout
+    # an unknown label: the reference's message and exit code (spmv.h:46-47)
+    r = run(exe, path, "cusp3")
+    assert r.returncode == 1 and 'SpMV kind "cusp3" is NOT SUPPROT' in r.stderr
+
+
+@pytest.mark.gpu
 def test_vendor_comparison_kinds_in_the_harness(exe):
     """`rocsparse` / `rocsparse_stream` (host/spmv/rocsparse_cmp.hpp): the place of `cusparse` in the reference's
     SPMV_KINDS (spmv.h:19), compiled into the harness only when rocSPARSE is there.  Same tables, same delta
