@@ -136,6 +136,17 @@ static RcclApi* rccl_api() {
         }                                                                                       \
     } while (0)
 
+// ncclGroupStart ... ncclGroupEnd: a call that fails in between must still close the group (an open group makes
+// every later RCCL call of the thread part of it)
+struct RcclGroup {
+    RcclApi* api;
+    bool open = false;
+    explicit RcclGroup(RcclApi* a) : api(a) {}
+    ncclResult_t start() { const ncclResult_t r = api->GroupStart(); open = r == ncclSuccess; return r; }
+    ncclResult_t end() { open = false; return api->GroupEnd(); }
+    ~RcclGroup() { if (open) (void)api->GroupEnd(); }
+};
+
 // out[i] = Ap[i] - base for i in [0, n]: the offsets of a row block, relative to the 16-byte-aligned element
 // its view of Aj / Ax starts at (so out[0] is the block's phase, 0..3)
 template <typename off_t>
@@ -436,10 +447,11 @@ int exchange_sub_block(mi355_spmv_dist* d, RcclApi* api, int s, YOf y_of) {
     const int wpv = int(vb / 4);                                   // 4-byte words per value
     const ncclDataType_t dt = d->val_type == MI355_VAL_F64 ? ncclFloat64 : ncclFloat32;
     auto blk = [&](int r) { return r * d->sub_blocks + s; };
+    RcclGroup group(api);
     switch (d->exchange) {
     case MI355_DIST_EXCHANGE_SENDRECV: {
         // every GPU sends its block to every peer and receives theirs: point to point, all links at once
-        MI355_RCCL_TRY(api, api->GroupStart());
+        MI355_RCCL_TRY(api, group.start());
         for (int i = 0; i < n_dev; ++i) {
             Dev& v = d->devs[size_t(i)];
             char* const yv = static_cast<char*>(y_of(i));
@@ -454,20 +466,20 @@ int exchange_sub_block(mi355_spmv_dist* d, RcclApi* api, int s, YOf y_of) {
                     MI355_RCCL_TRY(api, api->Recv(yv + size_t(d->row_cuts[size_t(blk(r))]) * vb, size_t(theirs), dt, r, v.nccl, v.comm));
             }
         }
-        MI355_RCCL_TRY(api, api->GroupEnd());
+        MI355_RCCL_TRY(api, group.end());
         return MI355_SPMV_OK;
     }
     case MI355_DIST_EXCHANGE_ALLGATHER: {
         if (d->gather_in_place[size_t(s)]) {
             // equal, adjacent blocks: the slices ARE the layout of an allgather (sendbuff = recvbuff + rank * count)
             const int64_t cnt = block_rows(*d, blk(0));
-            MI355_RCCL_TRY(api, api->GroupStart());
+            MI355_RCCL_TRY(api, group.start());
             for (int i = 0; i < n_dev; ++i) {
                 Dev& v = d->devs[size_t(i)];
                 char* const base = static_cast<char*>(y_of(i)) + size_t(d->row_cuts[size_t(blk(0))]) * vb;
                 MI355_RCCL_TRY(api, api->AllGather(base + size_t(rank_of(*d, i)) * size_t(cnt) * vb, base, size_t(cnt), dt, v.nccl, v.comm));
             }
-            MI355_RCCL_TRY(api, api->GroupEnd());
+            MI355_RCCL_TRY(api, group.end());
             return MI355_SPMV_OK;
         }
         const int64_t pad = d->max_block_rows;
@@ -485,13 +497,13 @@ int exchange_sub_block(mi355_spmv_dist* d, RcclApi* api, int s, YOf y_of) {
             MI355_HIP_TRY(hipSetDevice(v.device));
             if (const int st = launch_pieces(v.stage, y_of(i), pc, pc.n ? pc.words[0] : 0, v.comm)) return st;
         }
-        MI355_RCCL_TRY(api, api->GroupStart());
+        MI355_RCCL_TRY(api, group.start());
         for (int i = 0; i < n_dev; ++i) {
             Dev& v = d->devs[size_t(i)];
             char* const st = static_cast<char*>(v.stage);
             MI355_RCCL_TRY(api, api->AllGather(st + size_t(rank_of(*d, i)) * size_t(pad) * vb, st, size_t(pad), dt, v.nccl, v.comm));
         }
-        MI355_RCCL_TRY(api, api->GroupEnd());
+        MI355_RCCL_TRY(api, group.end());
         for (int i = 0; i < n_dev; ++i) {          // unpack: every other GPU's block to its displacement of y
             Dev& v = d->devs[size_t(i)];
             const int me = rank_of(*d, i);
@@ -515,7 +527,7 @@ int exchange_sub_block(mi355_spmv_dist* d, RcclApi* api, int s, YOf y_of) {
     default: {
         // block (root, s) travels from GPU `root` into the same displacement of every GPU's y — in place on the
         // root.  One group: all of them progress together.
-        MI355_RCCL_TRY(api, api->GroupStart());
+        MI355_RCCL_TRY(api, group.start());
         for (int i = 0; i < n_dev; ++i) {
             Dev& v = d->devs[size_t(i)];
             char* const yv = static_cast<char*>(y_of(i));
@@ -526,7 +538,7 @@ int exchange_sub_block(mi355_spmv_dist* d, RcclApi* api, int s, YOf y_of) {
                 MI355_RCCL_TRY(api, api->Broadcast(at, at, size_t(cnt), dt, root, v.nccl, v.comm));
             }
         }
-        MI355_RCCL_TRY(api, api->GroupEnd());
+        MI355_RCCL_TRY(api, group.end());
         return MI355_SPMV_OK;
     }
     }

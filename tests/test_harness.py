@@ -81,8 +81,8 @@ def test_unknown_kind_and_unit_flag(exe):
     r = run(exe, path, "hip_vector", "--iters", "5", "--unit-us")
     assert r.returncode == 0 and re.search(r"total: +[0-9.]+ us  kernel: +[0-9.]+ us", r.stdout)
     assert re.search(r"\[hip_vector  \] sum: +0\.000000  avg: +0\.000000", r.stdout)       # integer-valued: exact
-    r = run(exe, path, "cusparse")
-    assert r.returncode == 1 and 'SpMV kind "cusparse" is NOT SUPPROT' in r.stderr        # spmv.h:46-47
+    r = run(exe, path, "no_such_kind")
+    assert r.returncode == 1 and 'SpMV kind "no_such_kind" is NOT SUPPROT' in r.stderr    # spmv.h:46-47
 
 
 @pytest.mark.gpu
