@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI355_SPMV_VERSION 300 /* 0.3.0 */
+#define MI355_SPMV_VERSION 310 /* 0.3.1 */
 
 /* status codes */
 enum {
@@ -71,7 +71,8 @@ enum { MI355_VAL_F32 = 0, MI355_VAL_F64 = 1,
 /* semirings of the generalized merge kind.  The reference's
  * SpMV_merge_based_generalized takes a functor_t with initialize / combine / reduce
  * (include/spmv/merge_genl/merge_genl.cuh:19-38; CPU twin include/spmv/cpu_navie.hpp:20-34)
- * and ships (+, *); a C ABI cannot take a C++ functor and enumerates them instead:
+ * and ships (+, *); a C ABI cannot take a C++ functor: the tuned kernels enumerate these (any OTHER functor, and any
+ * mix of the five types, goes through mi355_spmv_functor_* below — its text compiled at run time):
  *   PLUS_TIMES  y[r] = sum_k  Ax[k] * x[Aj[k]]           (identity 0)      — every other entry point
  *   MIN_PLUS    y[r] = min_k (Ax[k] + x[Aj[k]])          (identity +inf; INT32_MAX for integers) — shortest-path relaxation
  *   MAX_TIMES   y[r] = max_k (Ax[k] * x[Aj[k]])          (identity -inf)   — widest / most reliable path
@@ -357,6 +358,34 @@ int mi355_spmv_plan_release(mi355_spmv_plan* plan, int executed_ok);
  * (synchronises).  Integers: compared bit-exactly with the oracle's restatement
  * of thread_search.cuh:15-49.                                                  */
 int mi355_spmv_plan_merge_coords(mi355_spmv_plan* plan, int64_t* tile_row, int64_t* tile_nnz);
+
+/* ---- a generalized SpMV whose functor is the CALLER'S code --------------------
+ * The reference's SpMV_merge_based_generalized is a template over a functor_t with three static members
+ * (include/spmv/merge_genl/merge_genl.cuh:19-38; CPU twin include/spmv/cpu_navie.hpp:20-34)
+ *     y_t initialize();   y_t combine(const mat_t& nonzero, const x_t& x);   y_t reduce(const y_t& lhs, const y_t& rhs);
+ * and over five independent types (include/spmv.h:29-34).  A C ABI cannot take a C++ type, but it can take its TEXT:
+ *   source        C++ source that defines the functor (and any type it needs); __host__ __device__ __forceinline__
+ *                 are understood, so a functor written for the reference is passed as it is (hiprtc has no
+ *                 <cmath>: INFINITY and NAN are defined in front of the text)
+ *   functor_type  the type to use, as written in C++: "MyFunctor", "MergeFunctor<float, float, double>"
+ *   off_type      MI355_OFF_I32 / MI355_OFF_I64;  index_t is int
+ *   mat_type, x_type, y_type   the three value types as C++ type names: "float", "double", "int", "long long", or a
+ *                 trivially copyable struct the source defines (an (value, index) pair for an arg-max, say)
+ * compile: the text is compiled for gfx950 at run time (hiprtc, bound on first use; no device needed);
+ *          MI355_SPMV_EINVAL = the text did not compile, mi355_spmv_functor_compile_log() holds the compiler's output
+ *          (this thread's last compile), MI355_SPMV_ENOTSUP = no libhiprtc.so on this machine.
+ * spmv:    y[r] = reduce over the row of combine(Ax[k], x[Aj[k]]) starting from initialize(), every row written
+ *          (an empty row gets initialize()).  Asynchronous on `stream`, no scratch, no host synchronisation.  As in the
+ *          reference's device code, reduce must be associative and commutative and initialize() its identity.
+ * This is the GENERAL path (T lanes per row, plain gathers of x); the five enumerated semirings of the merge kind
+ * above are the tuned one.                                                                                          */
+typedef struct mi355_spmv_functor mi355_spmv_functor;
+int mi355_spmv_functor_compile(mi355_spmv_functor** functor, const char* source, const char* functor_type, int off_type,
+                               const char* mat_type, const char* x_type, const char* y_type);
+const char* mi355_spmv_functor_compile_log(void);
+int mi355_spmv_functor_spmv(mi355_spmv_functor* functor, int32_t n_rows, int32_t n_cols, int64_t nnz, const void* Ap,
+                            const int32_t* Aj, const void* Ax, const void* x, void* y, void* stream);
+int mi355_spmv_functor_destroy(mi355_spmv_functor* functor);
 
 /* ---- misc ------------------------------------------------------------------ */
 int mi355_spmv_version(void);

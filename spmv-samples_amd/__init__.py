@@ -17,4 +17,4 @@ Contents (only what the hot path needs):
     load.py    ctypes binding of the Matrix Market loader (include/mi355_load.h, host/load.hpp)
 """
 from . import capi, dist, load, synth  # noqa: F401
-from .capi import DistPlan, Plan, PlanShape, spmv, spmv_genl, spmv_mixed  # noqa: F401
+from .capi import DistPlan, Functor, Plan, PlanShape, spmv, spmv_genl, spmv_mixed  # noqa: F401

@@ -38,6 +38,7 @@ EXPORTS = (
                                         "execute", "execute_ex", "set_exchange", "get_info", "structure_changed",
                                         "set_alpha_beta", "parts", "cuts", "part_info", "device_y", "device_x",
                                         "destroy")]
+    + ["mi355_spmv_functor_" + n for n in ("compile", "compile_log", "spmv", "destroy")]
 )
 
 
@@ -321,6 +322,52 @@ class Plan:
     def destroy(self):
         if self._h:
             lib().mi355_spmv_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+C_TYPE_NAMES = {torch.float32: "float", torch.float64: "double", torch.int32: "int", torch.int64: "long long"}
+
+
+class Functor:
+    """mi355_spmv_functor_*: a generalized SpMV whose functor is C++ source text, compiled for gfx950 at run time.
+
+    source        text defining the functor the way the reference writes one (merge_genl.cuh:19-38): a struct with
+                  static initialize() / combine(nonzero, x) / reduce(lhs, rhs)
+    functor_type  the type to use ("MyFunctor", "MergeFunctor<float, float, double>")
+    off_dtype     torch.int32 / torch.int64;  mat / x / y: torch dtypes or C++ type names (a struct of the source)
+    Compiling needs no device; .spmv() runs on the tensors' device, asynchronously on `stream`."""
+
+    def __init__(self, source, functor_type, off_dtype=torch.int32, mat=torch.float32, x=torch.float32, y=torch.float32):
+        self._h = C.c_void_p()
+        self.off_dtype = off_dtype
+        names = [t if isinstance(t, str) else C_TYPE_NAMES[t] for t in (mat, x, y)]
+        L = lib()
+        L.mi355_spmv_functor_compile.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, C.c_char_p,
+                                                 C.c_char_p, C.c_char_p]
+        L.mi355_spmv_functor_compile_log.restype = C.c_char_p
+        L.mi355_spmv_functor_spmv.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64] + [C.c_void_p] * 6
+        L.mi355_spmv_functor_destroy.argtypes = [C.c_void_p]
+        st = L.mi355_spmv_functor_compile(C.byref(self._h), source.encode(), functor_type.encode(), OFF_TYPES[off_dtype][0],
+                                          names[0].encode(), names[1].encode(), names[2].encode())
+        self.log = (L.mi355_spmv_functor_compile_log() or b"").decode(errors="replace")
+        _check(st, "mi355_spmv_functor_compile")
+
+    def spmv(self, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream=None):
+        _require_device(Ap, Aj, Ax, x, y)
+        if Ap.dtype != self.off_dtype or Aj.dtype != torch.int32:
+            raise TypeError("Functor.spmv: Ap must be %s and Aj int32" % self.off_dtype)
+        _check(lib().mi355_spmv_functor_spmv(self._h, n_rows, n_cols, nnz, Ap.data_ptr(), Aj.data_ptr(), Ax.data_ptr(),
+                                             x.data_ptr(), y.data_ptr(), _stream_ptr(stream)), "mi355_spmv_functor_spmv")
+
+    def destroy(self):
+        if self._h:
+            lib().mi355_spmv_functor_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

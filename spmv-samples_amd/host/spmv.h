@@ -23,6 +23,24 @@
 #include "spmv/rocsparse_cmp.hpp"
 #include "timer.hpp"
 
+// "hip_functor": the general path next to the tuned kinds in the harness's tables — the ordinary (+, *) written as a
+// functor's TEXT, the way a user of the reference's generalized kind writes one (merge_genl.cuh:19-38), compiled for
+// gfx950 on first use (SpMV_hip_functor, spmv/mi355.hpp).
+MI355_FUNCTOR(TimesThenPlus,
+    template <typename mat_value_t, typename vec_x_value_t, typename vec_y_value_t>
+    struct TimesThenPlus {
+        __host__ __device__ __forceinline__ static vec_y_value_t initialize() { return vec_y_value_t(0); }
+        __host__ __device__ __forceinline__ static vec_y_value_t combine(const mat_value_t& nonzero, const vec_x_value_t& x) {
+            return vec_y_value_t(nonzero) * vec_y_value_t(x);
+        }
+        __host__ __device__ __forceinline__ static vec_y_value_t reduce(const vec_y_value_t& lhs, const vec_y_value_t& rhs) { return lhs + rhs; }
+    };)
+template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t, typename vec_y_value_t>
+void SpMV_hip_functor_times_plus(index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap, const index_t* Aj,
+                                 const mat_value_t* Ax, const vec_x_value_t* x, vec_y_value_t* y) {
+    SpMV_hip_functor<TimesThenPlus_text>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);
+}
+
 // Vendor comparison columns (the place of "cusparse" in the reference's list, spmv.h:19): present
 // only in a build with -DMI355_WITH_ROCSPARSE, never part of the engine.
 #ifdef MI355_WITH_ROCSPARSE
@@ -56,6 +74,7 @@
     X("hip_merge", SpMV_hip_merge)                    \
     X("hip_light", SpMV_hip_light)                    \
     X("hip_merge_genl", SpMV_hip_merge_generalized)   \
+    X("hip_functor", SpMV_hip_functor_times_plus)     \
     X("hip_dist_vector", SpMV_hip_dist_vector)        \
     X("hip_dist_merge", SpMV_hip_dist_merge)          \
     X("hip_dist_light", SpMV_hip_dist_light)          \

@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 
 #include "../../../include/mi355_spmv.h"
@@ -209,4 +210,78 @@ void SpMV_hip_merge_generalized(index_t n_rows, index_t n_cols, offset_t nnz, co
                                 const index_t* Aj, const mat_value_t* Ax, const vec_x_value_t* x,
                                 vec_y_value_t* y) {
     ::mi355_host::run_kind(MI355_KIND_MERGE, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, functor_t::id);
+}
+
+// ---- a functor of the caller's own (the reference's functor_t, merge_genl.cuh:19-38) -------------------------------
+// The reference hands SpMV_merge_based_generalized a C++ type.  Here the kernels are compiled at run time from the
+// functor's TEXT (mi355_spmv_functor_*, include/mi355_spmv.h): MI355_FUNCTOR(Name, definition...) keeps the definition
+// as C++ for the host — the CPU twin SpMV_genl_cpu_navie<functor_t> (cpu_navie.hpp:20-34) takes the same type — and
+// as a string for the device, so the functor is written ONCE, the way the reference writes it:
+//
+//   MI355_FUNCTOR(SaturatingAdd,
+//       template <typename mat_value_t, typename vec_x_value_t, typename vec_y_value_t>
+//       struct SaturatingAdd {
+//           __host__ __device__ __forceinline__ static vec_y_value_t initialize() { return vec_y_value_t(0); }
+//           __host__ __device__ __forceinline__ static vec_y_value_t combine(const mat_value_t& a, const vec_x_value_t& x) { ... }
+//           __host__ __device__ __forceinline__ static vec_y_value_t reduce(const vec_y_value_t& l, const vec_y_value_t& r) { ... }
+//       };)
+//   SpMV_hip_functor<SaturatingAdd_text>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);          // a template over the three
+//   SpMV_hip_functor<SaturatingAdd_text, false>(...)                                      // a plain struct
+//
+// All five types of include/spmv.h:29-34 are free (float / double / int / long long values, int / long long offsets);
+// the code object is compiled once per instantiation and kept for the life of the process.
+#ifndef __HIPCC__
+#ifndef __host__
+#define __host__
+#endif
+#ifndef __device__
+#define __device__
+#endif
+#ifndef __forceinline__
+#define __forceinline__ inline
+#endif
+#endif
+#define MI355_FUNCTOR(NAME, ...)                           \
+    __VA_ARGS__                                            \
+    struct NAME##_text {                                   \
+        static const char* source() { return #__VA_ARGS__; } \
+        static const char* name() { return #NAME; }        \
+    };
+
+namespace mi355_host {
+template <typename T> struct c_type_name;
+template <> struct c_type_name<float> { static const char* get() { return "float"; } };
+template <> struct c_type_name<double> { static const char* get() { return "double"; } };
+template <> struct c_type_name<int> { static const char* get() { return "int"; } };
+template <> struct c_type_name<long long> { static const char* get() { return "long long"; } };
+template <> struct c_type_name<long> { static const char* get() { return "long long"; } };   // (LP64: the same 64 bits)
+}  // namespace mi355_host
+
+/// generalized SpMV with the caller's own functor (cf. SpMV_merge_based_generalized<functor_t>, merge_genl.cuh:41-79)
+template <typename functor_text, bool is_template = true, typename index_t, typename offset_t, typename mat_value_t,
+          typename vec_x_value_t, typename vec_y_value_t>
+void SpMV_hip_functor(index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap, const index_t* Aj,
+                      const mat_value_t* Ax, const vec_x_value_t* x, vec_y_value_t* y) {
+    static_assert(sizeof(index_t) == 4, "mi355 kinds: index_t must be a 32-bit int (reference main.cu:15)");
+    static_assert(sizeof(offset_t) == 4 || sizeof(offset_t) == 8, "mi355 kinds: offset_t must be 32- or 64-bit");
+    static mi355_spmv_functor* compiled = [] {
+        std::string type = functor_text::name();
+        if (is_template)
+            type += std::string("<") + ::mi355_host::c_type_name<mat_value_t>::get() + ", " +
+                    ::mi355_host::c_type_name<vec_x_value_t>::get() + ", " + ::mi355_host::c_type_name<vec_y_value_t>::get() + ">";
+        mi355_spmv_functor* f = nullptr;
+        const int st = mi355_spmv_functor_compile(&f, functor_text::source(), type.c_str(),
+                                                  sizeof(offset_t) == 8 ? MI355_OFF_I64 : MI355_OFF_I32,
+                                                  ::mi355_host::c_type_name<mat_value_t>::get(),
+                                                  ::mi355_host::c_type_name<vec_x_value_t>::get(),
+                                                  ::mi355_host::c_type_name<vec_y_value_t>::get());
+        if (st != MI355_SPMV_OK) std::fprintf(stderr, "%s\n", mi355_spmv_functor_compile_log());
+        MI355_CHECK(st);
+        return f;
+    }();
+    Timer::kernel_start();
+    MI355_CHECK(mi355_spmv_functor_spmv(compiled, (int32_t)n_rows, (int32_t)n_cols, (int64_t)nnz, Ap,
+                                        reinterpret_cast<const int32_t*>(Aj), Ax, x, y, /*stream=*/nullptr));
+    MI355_CHECK(mi355_spmv_stream_synchronize(/*stream=*/nullptr));
+    Timer::kernel_stop();
 }

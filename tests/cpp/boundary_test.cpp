@@ -7,6 +7,7 @@
 //   boundary_test                 all labels x {i32,i64} x {f32,f64}; exit 0 when all pass
 //   boundary_test --bad-label     calls SpMV("no_such_kind", ...): must print the
 //                                 reference's message and exit(EXIT_FAILURE) (spmv.h:46-47)
+//   boundary_test --functor       functors of the caller's own through SpMV_hip_functor (compiled at run time)
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -209,6 +210,100 @@ static int run_integer() {
     return failures;
 }
 
+// Functors of the caller's own, written ONCE (MI355_FUNCTOR, host/spmv/mi355.hpp): the host compiles the definition for
+// the serial twin below, the device gets its text (hiprtc).  All five types of include/spmv.h:29-34 differ.
+MI355_FUNCTOR(ManhattanTerm,
+    template <typename mat_value_t, typename vec_x_value_t, typename vec_y_value_t>
+    struct ManhattanTerm {     // y[r] = sum_k |Ax[k] - x[Aj[k]]|
+        __host__ __device__ __forceinline__ static vec_y_value_t initialize() { return vec_y_value_t(0); }
+        __host__ __device__ __forceinline__ static vec_y_value_t combine(const mat_value_t& nonzero, const vec_x_value_t& x) {
+            const vec_y_value_t d = vec_y_value_t(nonzero) - vec_y_value_t(x);
+            return d < vec_y_value_t(0) ? -d : d;
+        }
+        __host__ __device__ __forceinline__ static vec_y_value_t reduce(const vec_y_value_t& lhs, const vec_y_value_t& rhs) { return lhs + rhs; }
+    };)
+MI355_FUNCTOR(Bottleneck,
+    template <typename mat_value_t, typename vec_x_value_t, typename vec_y_value_t>
+    struct Bottleneck {        // y[r] = max_k min(Ax[k], x[Aj[k]]): the widest path through one more edge
+        __host__ __device__ __forceinline__ static vec_y_value_t initialize() { return vec_y_value_t(-1.0e30); }
+        __host__ __device__ __forceinline__ static vec_y_value_t combine(const mat_value_t& nonzero, const vec_x_value_t& x) {
+            return vec_y_value_t(nonzero) < vec_y_value_t(x) ? vec_y_value_t(nonzero) : vec_y_value_t(x);
+        }
+        __host__ __device__ __forceinline__ static vec_y_value_t reduce(const vec_y_value_t& lhs, const vec_y_value_t& rhs) { return lhs < rhs ? rhs : lhs; }
+    };)
+MI355_FUNCTOR(CountPositive,
+    struct CountPositive {     // a plain struct: y[r] = how many products Ax[k] * x[Aj[k]] are positive
+        __host__ __device__ static long long initialize() { return 0; }
+        __host__ __device__ static long long combine(const double& nonzero, const float& x) { return nonzero * x > 0 ? 1 : 0; }
+        __host__ __device__ static long long reduce(const long long& lhs, const long long& rhs) { return lhs + rhs; }
+    };)
+
+// the serial fold every generalized kind is checked against (what cpu_navie.hpp:20-34 computes), in test code
+template <typename functor_t, typename offset_t, typename mat_t, typename x_t, typename y_t>
+static void fold_rows(int n_rows, const offset_t* Ap, const int* Aj, const mat_t* Ax, const x_t* x, y_t* y) {
+    for (int r = 0; r < n_rows; ++r) {
+        y_t acc = functor_t::initialize();
+        for (offset_t k = Ap[r]; k < Ap[r + 1]; ++k) acc = functor_t::reduce(acc, functor_t::combine(Ax[k], x[Aj[k]]));
+        y[r] = acc;
+    }
+}
+
+template <typename text_t, bool is_template, typename functor_t, typename offset_t, typename mat_t, typename x_t, typename y_t>
+static int run_functor_case(const char* what, int n_rows, int n_cols, int max_len, int hub_len) {
+    unsigned long long seed = 777 + (unsigned long long)n_rows;
+    std::vector<offset_t> Ap(n_rows + 1, 0);
+    std::vector<int> Aj;
+    std::vector<mat_t> Ax;
+    for (int r = 0; r < n_rows; ++r) {
+        int len = (r % 11 == 5) ? 0 : int(lcg(seed) % (unsigned)(max_len + 1));
+        if (r == n_rows / 3) len = hub_len;               // one row for the whole-wave kernel
+        for (int k = 0; k < len; ++k) {
+            Aj.push_back(int(lcg(seed) % (unsigned)n_cols));
+            Ax.push_back(mat_t(int(lcg(seed) % 201u) - 100));   // integer-valued: sums are exact in any order
+        }
+        Ap[r + 1] = offset_t(Aj.size());
+    }
+    const offset_t nnz = offset_t(Aj.size());
+    std::vector<x_t> x(n_cols);
+    for (int c = 0; c < n_cols; ++c) x[c] = x_t(int(lcg(seed) % 151u) - 75);
+    std::vector<y_t> want(n_rows), got(n_rows);
+    fold_rows<functor_t>(n_rows, Ap.data(), Aj.data(), Ax.data(), x.data(), want.data());
+    offset_t* dAp; int* dAj; mat_t* dAx; x_t* dX; y_t* dY;
+    HIP_OK(hipMalloc((void**)&dAp, (n_rows + 1) * sizeof(offset_t)));
+    HIP_OK(hipMalloc((void**)&dAj, (size_t(nnz) + 4) * sizeof(int)));
+    HIP_OK(hipMalloc((void**)&dAx, (size_t(nnz) + 4) * sizeof(mat_t)));
+    HIP_OK(hipMalloc((void**)&dX, n_cols * sizeof(x_t)));
+    HIP_OK(hipMalloc((void**)&dY, n_rows * sizeof(y_t)));
+    HIP_OK(hipMemcpy(dAp, Ap.data(), (n_rows + 1) * sizeof(offset_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dAj, Aj.data(), size_t(nnz) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dAx, Ax.data(), size_t(nnz) * sizeof(mat_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dX, x.data(), n_cols * sizeof(x_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(dY, 0x5a, n_rows * sizeof(y_t)));
+    int bad = 0;
+    for (int call = 0; call < 2; ++call) {                 // (the second call reuses the compiled code object)
+        SpMV_hip_functor<text_t, is_template>(n_rows, n_cols, nnz, dAp, dAj, dAx, dX, dY);
+        HIP_OK(hipMemcpy(got.data(), dY, n_rows * sizeof(y_t), hipMemcpyDeviceToHost));
+        for (int r = 0; r < n_rows; ++r) bad += got[r] == want[r] ? 0 : 1;
+    }
+    std::printf("[functor        ] %s rows=%d nnz=%lld bad_rows=%d kernel_us=%lld\n", what, n_rows, (long long)nnz, bad,
+                (long long)Timer::kernel_cost());
+    HIP_OK(hipFree(dAp)); HIP_OK(hipFree(dAj)); HIP_OK(hipFree(dAx)); HIP_OK(hipFree(dX)); HIP_OK(hipFree(dY));
+    return bad ? 1 : 0;
+}
+
+//   boundary_test --functor
+static int run_functor() {
+    int failures = 0;
+    failures += run_functor_case<ManhattanTerm_text, true, ManhattanTerm<float, int, double>, long long, float, int, double>(
+        "sum |a - x|  (i64 offsets, float matrix, int x, double y)", 20011, 3000, 40, 9000);
+    failures += run_functor_case<Bottleneck_text, true, Bottleneck<float, double, float>, int, float, double, float>(
+        "max min(a, x)  (i32 offsets, float matrix, double x, float y)", 7001, 500, 6, 3000);
+    failures += run_functor_case<CountPositive_text, false, CountPositive, int, double, float, long long>(
+        "count a * x > 0  (plain struct; double matrix, float x, long long y)", 4099, 4099, 150, 100);
+    std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
+    return failures ? 1 : 0;
+}
+
 // The multi-GPU kinds keep a handle that holds COPIES of the structure; SpMV(kind, ...) reads its arrays on every call
 // (the reference has no state between calls).  So: a call, then the matrix rewritten IN PLACE — other row lengths and
 // columns, same sizes, same addresses — and the values and x as well, then a second call that must see all of it.
@@ -270,6 +365,7 @@ static int run_dist_rewrite(int gpus) {
 int main(int argc, char** argv) {
     HIP_OK(hipSetDevice(0));  // USED_DEVICE 0 (common.cuh:8)
     if (argc > 1 && std::strcmp(argv[1], "--dist-rewrite") == 0) return run_dist_rewrite(argc > 2 ? std::atoi(argv[2]) : 1);
+    if (argc > 1 && std::strcmp(argv[1], "--functor") == 0) return run_functor();
     if (argc > 1 && std::strcmp(argv[1], "--bad-label") == 0) {
         int* d;
         HIP_OK(hipMalloc((void**)&d, 64));

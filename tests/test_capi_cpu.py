@@ -55,7 +55,7 @@ def test_loader_library_exports_every_declared_symbol_and_loads_a_fixture(sp):
 
 def test_version_and_status_strings(sp):
     lib = sp.capi.lib()
-    assert lib.mi355_spmv_version() == 300
+    assert lib.mi355_spmv_version() == 310
     assert lib.mi355_spmv_status_string(0) == b"ok"
     assert lib.mi355_spmv_status_string(1) == b"invalid argument"
     assert lib.mi355_spmv_status_string(99) == b"unknown status"

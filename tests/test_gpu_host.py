@@ -52,6 +52,17 @@ def test_cpp_dist_kinds_see_a_matrix_rewritten_in_place(gpus):
     assert r.stdout.count("rewritten in place bad_rows=0") == 3
 
 
+def test_cpp_functors_written_once_for_host_and_device():
+    """SpMV_hip_functor<Text>(...) (host/spmv/mi355.hpp): MI355_FUNCTOR keeps ONE definition of a functor — the shape of
+    the reference's functor_t, merge_genl.cuh:19-38 — as C++ for the serial host fold (what cpu_navie.hpp:20-34 computes)
+    and as text for the device (hiprtc).  Three functors of the test's own, five distinct types each, exact results."""
+    _build_exe()
+    r = subprocess.run([EXE, "--functor"], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("bad_rows=0") == 3
+
+
 def test_cpp_boundary_unknown_label_exits_like_the_reference():
     """spmv.h:46-47: message on stderr and exit(EXIT_FAILURE)."""
     _build_exe()
