@@ -24,17 +24,8 @@
 #include "timer.hpp"
 
 // "hip_functor": the general path next to the tuned kinds in the harness's tables — the ordinary (+, *) written as a
-// functor's TEXT, the way a user of the reference's generalized kind writes one (merge_genl.cuh:19-38), compiled for
-// gfx950 on first use (SpMV_hip_functor, spmv/mi355.hpp).
-MI355_FUNCTOR(TimesThenPlus,
-    template <typename mat_value_t, typename vec_x_value_t, typename vec_y_value_t>
-    struct TimesThenPlus {
-        __host__ __device__ __forceinline__ static vec_y_value_t initialize() { return vec_y_value_t(0); }
-        __host__ __device__ __forceinline__ static vec_y_value_t combine(const mat_value_t& nonzero, const vec_x_value_t& x) {
-            return vec_y_value_t(nonzero) * vec_y_value_t(x);
-        }
-        __host__ __device__ __forceinline__ static vec_y_value_t reduce(const vec_y_value_t& lhs, const vec_y_value_t& rhs) { return lhs + rhs; }
-    };)
+// functor's TEXT (TimesThenPlus, spmv/mi355.hpp), the way a user of the reference's generalized kind writes one
+// (merge_genl.cuh:19-38), compiled for gfx950 on first use (SpMV_hip_functor).
 template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t, typename vec_y_value_t>
 void SpMV_hip_functor_times_plus(index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap, const index_t* Aj,
                                  const mat_value_t* Ax, const vec_x_value_t* x, vec_y_value_t* y) {

@@ -48,6 +48,11 @@ struct MaxTimes  { static constexpr int id = MI355_SEMIRING_MAX_TIMES; };
 struct MaxPlus   { static constexpr int id = MI355_SEMIRING_MAX_PLUS; };
 struct OrAnd     { static constexpr int id = MI355_SEMIRING_OR_AND; };     // booleans as 0.0 / 1.0 (or 0 / 1 on int values)
 
+// (+, *) for any mix of value types, on the functor-text path (defined at the end of this file)
+template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t, typename vec_y_value_t>
+void run_general(index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap, const index_t* Aj,
+                 const mat_value_t* Ax, const vec_x_value_t* x, vec_y_value_t* y);
+
 template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,
           typename vec_y_value_t>
 void run_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap, const index_t* Aj,
@@ -58,18 +63,26 @@ void run_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const offs
     static_assert(sizeof(offset_t) == 4 || sizeof(offset_t) == 8, "mi355 kinds: offset_t must be 32- or 64-bit");
     static_assert(std::is_integral<offset_t>::value && std::is_signed<offset_t>::value,
                   "mi355 kinds: offset_t must be a signed integer");
-    // A, x and y share one value type (reference main.cu:17) — or, for the merge kinds, an fp32 matrix sits under
-    // fp64 vectors (the reference's template keeps the three apart, spmv.h:29-34; merge_genl.cuh:29-31 computes in
-    // the y type).  Anything else is not built: mi355_spmv_plan_create_typed returns ENOTSUP and the check aborts.
-    static_assert(std::is_same<vec_x_value_t, vec_y_value_t>::value, "mi355 kinds: x and y share one value type");
-    // ... or 32-bit integers throughout (the merge kinds: every semiring of the generalized kind, exact)
-    constexpr bool all_int = std::is_same<mat_value_t, int>::value && std::is_same<vec_x_value_t, int>::value;
-    static_assert(all_int || ((std::is_same<mat_value_t, float>::value || std::is_same<mat_value_t, double>::value) &&
-                              (std::is_same<vec_x_value_t, float>::value || std::is_same<vec_x_value_t, double>::value)),
-                  "mi355 kinds: value types are float or double (or int throughout, merge kinds)");
-    static_assert(std::is_same<mat_value_t, vec_x_value_t>::value ||
-                      (std::is_same<mat_value_t, float>::value && std::is_same<vec_x_value_t, double>::value),
-                  "mi355 kinds: the only mixed combination is an fp32 matrix under fp64 vectors");
+    // The TUNED kernels are built for: A, x and y of one floating-point type (reference main.cu:17; every kind); an fp32
+    // matrix under fp64 vectors and 32-bit integers throughout (the merge kinds).  The reference's template keeps the
+    // three value types apart (spmv.h:29-34; merge_genl.cuh:29-31 computes in the y type): every OTHER mix of float /
+    // double / int / long long runs the ordinary (+, *) on the general path — the functor-text kernels, compiled at
+    // run time for exactly these types (run_general below) — so that every kind accepts what the reference's does.
+    constexpr bool is_fp_mat = std::is_same<mat_value_t, float>::value || std::is_same<mat_value_t, double>::value;
+    constexpr bool same3 = std::is_same<mat_value_t, vec_x_value_t>::value && std::is_same<vec_x_value_t, vec_y_value_t>::value;
+    constexpr bool all_int = same3 && std::is_same<mat_value_t, int>::value;
+    constexpr bool f32_under_f64 = std::is_same<mat_value_t, float>::value && std::is_same<vec_x_value_t, double>::value &&
+                                   std::is_same<vec_y_value_t, double>::value;
+    const bool tuned = (same3 && is_fp_mat) || ((all_int || f32_under_f64) && kind == MI355_KIND_MERGE);
+    if (!tuned) {
+        if (semiring != MI355_SEMIRING_PLUS_TIMES) {
+            std::fprintf(stderr, "mi355 kinds: the enumerated semirings other than (+, *) are built for one value type; "
+                                 "pass a functor's text to SpMV_hip_functor for these types\n");
+            std::abort();
+        }
+        run_general(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);
+        return;
+    }
     const int off_type = sizeof(offset_t) == 8 ? MI355_OFF_I64 : MI355_OFF_I32;
     const int mat_type = all_int ? MI355_VAL_I32 : std::is_same<mat_value_t, double>::value ? MI355_VAL_F64 : MI355_VAL_F32;
     const int vec_type = all_int ? MI355_VAL_I32 : std::is_same<vec_x_value_t, double>::value ? MI355_VAL_F64 : MI355_VAL_F32;
@@ -285,3 +298,23 @@ void SpMV_hip_functor(index_t n_rows, index_t n_cols, offset_t nnz, const offset
     MI355_CHECK(mi355_spmv_stream_synchronize(/*stream=*/nullptr));
     Timer::kernel_stop();
 }
+
+// the ordinary (+, *) as a functor's text: what run_kind falls back on for the type mixes the tuned kernels are not
+// built for, and the harness's "hip_functor" row (host/spmv.h)
+MI355_FUNCTOR(TimesThenPlus,
+    template <typename mat_value_t, typename vec_x_value_t, typename vec_y_value_t>
+    struct TimesThenPlus {
+        __host__ __device__ __forceinline__ static vec_y_value_t initialize() { return vec_y_value_t(0); }
+        __host__ __device__ __forceinline__ static vec_y_value_t combine(const mat_value_t& nonzero, const vec_x_value_t& x) {
+            return vec_y_value_t(nonzero * x);     // (the product in the promoted type, then the y type: merge_genl.cuh:29-31)
+        }
+        __host__ __device__ __forceinline__ static vec_y_value_t reduce(const vec_y_value_t& lhs, const vec_y_value_t& rhs) { return lhs + rhs; }
+    };)
+
+namespace mi355_host {
+template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t, typename vec_y_value_t>
+void run_general(index_t n_rows, index_t n_cols, offset_t nnz, const offset_t* Ap, const index_t* Aj,
+                 const mat_value_t* Ax, const vec_x_value_t* x, vec_y_value_t* y) {
+    ::SpMV_hip_functor<TimesThenPlus_text>(n_rows, n_cols, nnz, Ap, Aj, Ax, x, y);
+}
+}  // namespace mi355_host

@@ -291,9 +291,59 @@ static int run_functor_case(const char* what, int n_rows, int n_cols, int max_le
     return bad ? 1 : 0;
 }
 
+// Every kind accepts any mix of float / double / int / long long for the matrix, x and y, as the reference's templates do
+// (spmv.h:29-34): what the tuned kernels are not built for runs (+, *) on the general path.  Integer-valued data: exact.
+template <typename offset_t, typename mat_t, typename x_t, typename y_t, typename Call>
+static int run_untuned_mix(const char* what, Call call) {
+    const int n_rows = 5003, n_cols = 1200;
+    unsigned long long seed = 31337;
+    std::vector<offset_t> Ap(n_rows + 1, 0);
+    std::vector<int> Aj;
+    std::vector<mat_t> Ax;
+    for (int r = 0; r < n_rows; ++r) {
+        const int len = (r % 9 == 2) ? 0 : int(lcg(seed) % 33u);
+        for (int k = 0; k < len; ++k) {
+            Aj.push_back(int(lcg(seed) % (unsigned)n_cols));
+            Ax.push_back(mat_t(int(lcg(seed) % 21u) - 10));
+        }
+        Ap[r + 1] = offset_t(Aj.size());
+    }
+    const offset_t nnz = offset_t(Aj.size());
+    std::vector<x_t> x(n_cols);
+    for (int c = 0; c < n_cols; ++c) x[c] = x_t(int(lcg(seed) % 15u) - 7);
+    std::vector<y_t> want(n_rows), got(n_rows);
+    fold_rows<TimesThenPlus<mat_t, x_t, y_t>>(n_rows, Ap.data(), Aj.data(), Ax.data(), x.data(), want.data());
+    offset_t* dAp; int* dAj; mat_t* dAx; x_t* dX; y_t* dY;
+    HIP_OK(hipMalloc((void**)&dAp, (n_rows + 1) * sizeof(offset_t)));
+    HIP_OK(hipMalloc((void**)&dAj, (size_t(nnz) + 4) * sizeof(int)));
+    HIP_OK(hipMalloc((void**)&dAx, (size_t(nnz) + 4) * sizeof(mat_t)));
+    HIP_OK(hipMalloc((void**)&dX, n_cols * sizeof(x_t)));
+    HIP_OK(hipMalloc((void**)&dY, n_rows * sizeof(y_t)));
+    HIP_OK(hipMemcpy(dAp, Ap.data(), (n_rows + 1) * sizeof(offset_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dAj, Aj.data(), size_t(nnz) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dAx, Ax.data(), size_t(nnz) * sizeof(mat_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dX, x.data(), n_cols * sizeof(x_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(dY, 0x5a, n_rows * sizeof(y_t)));
+    call(n_rows, n_cols, nnz, dAp, dAj, dAx, dX, dY);
+    HIP_OK(hipMemcpy(got.data(), dY, n_rows * sizeof(y_t), hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int r = 0; r < n_rows; ++r) bad += got[r] == want[r] ? 0 : 1;
+    std::printf("[untuned mix    ] %s rows=%d nnz=%lld bad_rows=%d\n", what, n_rows, (long long)nnz, bad);
+    HIP_OK(hipFree(dAp)); HIP_OK(hipFree(dAj)); HIP_OK(hipFree(dAx)); HIP_OK(hipFree(dX)); HIP_OK(hipFree(dY));
+    return bad ? 1 : 0;
+}
+
 //   boundary_test --functor
 static int run_functor() {
     int failures = 0;
+    failures += run_untuned_mix<int, double, float, float>("SpMV_hip_vector<int, int, double, float, float>",
+        [](int r, int c, int z, const int* p, const int* j, const double* a, const float* x, float* y) { SpMV_hip_vector(r, c, z, p, j, a, x, y); });
+    failures += run_untuned_mix<long long, float, float, double>("SpMV_hip_light<int, long long, float, float, double>",
+        [](int r, int c, long long z, const long long* p, const int* j, const float* a, const float* x, double* y) { SpMV_hip_light(r, c, z, p, j, a, x, y); });
+    failures += run_untuned_mix<int, int, int, long long>("SpMV_hip_merge<int, int, int, int, long long>",
+        [](int r, int c, int z, const int* p, const int* j, const int* a, const int* x, long long* y) { SpMV_hip_merge(r, c, z, p, j, a, x, y); });
+    failures += run_untuned_mix<int, int, int, int>("SpMV_hip_vector<int, int, int, int, int>  (integers are tuned for merge only)",
+        [](int r, int c, int z, const int* p, const int* j, const int* a, const int* x, int* y) { SpMV_hip_vector(r, c, z, p, j, a, x, y); });
     failures += run_functor_case<ManhattanTerm_text, true, ManhattanTerm<float, int, double>, long long, float, int, double>(
         "sum |a - x|  (i64 offsets, float matrix, int x, double y)", 20011, 3000, 40, 9000);
     failures += run_functor_case<Bottleneck_text, true, Bottleneck<float, double, float>, int, float, double, float>(

@@ -60,7 +60,9 @@ def test_cpp_functors_written_once_for_host_and_device():
     r = subprocess.run([EXE, "--functor"], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout + r.stderr
-    assert r.stdout.count("bad_rows=0") == 3
+    assert r.stdout.count("bad_rows=0") == 7
+    # ... and the kinds themselves on type mixes the tuned kernels are not built for (spmv.h:29-34: five free types)
+    assert r.stdout.count("[untuned mix    ]") == 4
 
 
 def test_cpp_boundary_unknown_label_exits_like_the_reference():
