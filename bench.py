@@ -665,6 +665,15 @@ def main():
                                    "ms_per_step)" if legs else "")},
             "warmup_probe_ms": probe,
         }
+        if not use_dist:
+            # what the library itself would run for a caller with no opinion (MI355_KIND_AUTO: a rule on the structure,
+            # no timing) — reported next to the measured pick
+            try:
+                pa = sp.Plan("auto", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype)
+                out["library_auto_kind"] = sp.capi.KIND_NAMES[pa.info()["kind"]]
+                pa.destroy()
+            except Exception as e:            # (never fails the bench line)
+                out["library_auto_kind"] = "error: %s" % e
         if probe:
             out["kind_pick"] = "every kind warmed for %d executes, then 7 interleaved rounds of 10; median per kind%s" % (
                 max(args.warmup, 70), ", max over ranks" if multi else "")

@@ -59,7 +59,14 @@ enum {
  *   LIGHT   dynamic row distribution from global atomic row counters
  *           (replaces SpMV_light_vector / SpMV_light_warp,
  *            include/spmv/LightSpMV.cuh:379-416)                              */
-enum { MI355_KIND_VECTOR = 0, MI355_KIND_MERGE = 1, MI355_KIND_LIGHT = 2, MI355_KIND_COUNT = 3 };
+enum { MI355_KIND_VECTOR = 0, MI355_KIND_MERGE = 1, MI355_KIND_LIGHT = 2, MI355_KIND_COUNT = 3,
+       /* plan_create / plan_acquire / the mi355_spmv_auto_* one-shots / dist_create_local only: the library picks.  The
+        * reference leaves the choice of kind to the command line (main.cu:26-30); a caller that has no opinion gets
+        * MERGE when the row lengths are skewed (the heaviest run of rows a workgroup would take holds more than twice
+        * the mean: power-law matrices, where merge-path is ahead of the row kinds on every measured config) and for
+        * integer values, VECTOR otherwise.  A heuristic on structure, not a measurement (bench.py measures);
+        * plan_get_info().kind reports what was picked.                                                            */
+       MI355_KIND_AUTO = 100 };
 enum { MI355_OFF_I32 = 0, MI355_OFF_I64 = 1 };
 enum { MI355_VAL_F32 = 0, MI355_VAL_F64 = 1,
        /* 32-bit integers: the MERGE kind only (every semiring; two's-complement wrap-around, exact whatever the
@@ -111,6 +118,7 @@ enum {
 MI355_SPMV_DECLARE_KIND(vector) /* replaces SpMV_cusp_warp_reduce  cusp_warp_reduce.cuh:138 */
 MI355_SPMV_DECLARE_KIND(merge)  /* replaces SpMV_merge_based[_generalized] merge_based.cuh:22, merge_genl.cuh:41 */
 MI355_SPMV_DECLARE_KIND(light)  /* replaces SpMV_light_vector/_warp  LightSpMV.cuh:379, :400 */
+MI355_SPMV_DECLARE_KIND(auto)   /* MI355_KIND_AUTO: one of the three, picked from the structure */
 
 /* generalized merge-path SpMV: the reference's SpMV_merge_based_generalized
  * (include/spmv/merge_genl/merge_genl.cuh:41-79) with the semiring as an argument.  */

@@ -15,9 +15,10 @@ import torch  # imported before the library so both share one HIP runtime
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355_SPMV_LIB") or os.path.join(_HERE, "lib", "libmi355spmv.so")
 
-KINDS = {"vector": 0, "merge": 1, "light": 2}
+KINDS = {"vector": 0, "merge": 1, "light": 2, "auto": 100}   # auto: the library picks (MI355_KIND_AUTO)
+KIND_NAMES = {0: "vector", 1: "merge", 2: "light"}
 # labels the C++ host header registers in SPMV_KINDS (host/spmv.h)
-LABELS = {"hip_vector": "vector", "hip_merge": "merge", "hip_light": "light"}
+LABELS = {"hip_vector": "vector", "hip_merge": "merge", "hip_light": "light", "hip_auto": "auto"}
 OFF_TYPES = {torch.int32: (0, "i32"), torch.int64: (1, "i64")}
 VAL_TYPES = {torch.float32: (0, "f32"), torch.float64: (1, "f64"), torch.int32: (2, "i32")}   # (int32 values: the merge kind only)
 PLAN_REUSE_STRUCTURE = 1
@@ -171,7 +172,7 @@ def spmv(kind, n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream=None):
     if Aj.dtype != torch.int32 or Ax.dtype != x.dtype or Ax.dtype != y.dtype:
         raise TypeError("Aj must be int32 and Ax, x, y one value type")
     if Ax.dtype == torch.int32:            # integer values exist for the (generalized) merge kind only
-        if LABELS.get(kind, kind) != "merge":
+        if LABELS.get(kind, kind) not in ("merge", "auto"):
             raise RuntimeError("mi355_spmv: integer values are not supported by the %s kind (merge only)" % kind)
         return spmv_genl("plus_times", n_rows, n_cols, nnz, Ap, Aj, Ax, x, y, stream)
     o = OFF_TYPES[Ap.dtype][1]

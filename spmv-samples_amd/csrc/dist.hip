@@ -703,6 +703,7 @@ int mi355_spmv_dist_create_local(mi355_spmv_dist** out, int kind, int off_type, 
     d->chunk_cuts.resize(size_t(parts) + 1);
     d->nnz_cuts.resize(size_t(parts) + 1);
     st = mi355_spmv_plan_get_shape(whole, &shape);
+    if (st == MI355_SPMV_OK) d->kind = kind = shape.kind;       // (MI355_KIND_AUTO: what the whole matrix's plan picked)
     if (st == MI355_SPMV_OK)
         st = mi355_spmv_plan_partition(whole, parts, d->row_cuts.data(), d->chunk_cuts.data(), d->nnz_cuts.data());
     (void)mi355_spmv_plan_destroy(whole);

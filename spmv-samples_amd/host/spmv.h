@@ -64,6 +64,7 @@ void SpMV_hip_functor_times_plus(index_t n_rows, index_t n_cols, offset_t nnz, c
     X("hip_vector", SpMV_hip_vector)                  \
     X("hip_merge", SpMV_hip_merge)                    \
     X("hip_light", SpMV_hip_light)                    \
+    X("hip_auto", SpMV_hip_auto)                      \
     X("hip_merge_genl", SpMV_hip_merge_generalized)   \
     X("hip_functor", SpMV_hip_functor_times_plus)     \
     X("hip_dist_vector", SpMV_hip_dist_vector)        \

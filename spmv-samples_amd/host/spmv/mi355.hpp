@@ -73,6 +73,7 @@ void run_kind(int kind, index_t n_rows, index_t n_cols, offset_t nnz, const offs
     constexpr bool all_int = same3 && std::is_same<mat_value_t, int>::value;
     constexpr bool f32_under_f64 = std::is_same<mat_value_t, float>::value && std::is_same<vec_x_value_t, double>::value &&
                                    std::is_same<vec_y_value_t, double>::value;
+    if (kind == MI355_KIND_AUTO && (all_int || f32_under_f64)) kind = MI355_KIND_MERGE;   // (what the library would pick)
     const bool tuned = (same3 && is_fp_mat) || ((all_int || f32_under_f64) && kind == MI355_KIND_MERGE);
     if (!tuned) {
         if (semiring != MI355_SEMIRING_PLUS_TIMES) {
@@ -202,6 +203,9 @@ MI355_DEFINE_KIND(SpMV_hip_vector, MI355_KIND_VECTOR)
 MI355_DEFINE_KIND(SpMV_hip_merge, MI355_KIND_MERGE)
 /// LightSpMV-style dynamic row distribution (sharded atomic row counters)
 MI355_DEFINE_KIND(SpMV_hip_light, MI355_KIND_LIGHT)
+
+/// one of the three, picked by the library from the matrix's structure (MI355_KIND_AUTO, include/mi355_spmv.h)
+MI355_DEFINE_KIND(SpMV_hip_auto, MI355_KIND_AUTO)
 
 #define MI355_DEFINE_DIST_KIND(NAME, KIND)                                                                     \
     template <typename index_t, typename offset_t, typename mat_value_t, typename vec_x_value_t,               \

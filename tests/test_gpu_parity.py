@@ -1139,3 +1139,46 @@ def test_merge_on_a_regular_matrix_takes_row_parallel_runs(sp, oracle):
     if "MI355_MERGE_ROWS" not in os.environ:
         assert p.info()["main_kernel"] == "merge_tile_kernel"
     p.destroy()
+
+
+# ---- MI355_KIND_AUTO: the library picks the kind ---------------------------------------------------------------
+
+def test_auto_kind_picks_merge_on_skewed_rows_and_vector_otherwise(sp, oracle):
+    """The reference leaves the kind to the command line (main.cu:26-30).  MI355_KIND_AUTO: merge-path when the row
+    lengths are skewed (the VECTOR plan's own analysis had to cut its chunks by weight), VECTOR otherwise; integer
+    values are merge's.  Whatever is picked, the result is that kind's result, bit for bit."""
+    band = sp.synth.banded_fixed(1 << 16, 32, 2048, 1, DEV)
+    skew = sp.synth.rmat(16, 16, seed=5, device=DEV)
+    for m, want in ((band, "vector"), (skew, "merge")):
+        x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, DEV)
+        p = sp.Plan("auto", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype)
+        assert sp.capi.KIND_NAMES[p.info()["kind"]] == want
+        q = sp.Plan(want, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype)
+        y = torch.full((m.n_rows,), float("nan"), device=DEV)
+        y2 = torch.full((m.n_rows,), float("nan"), device=DEV)
+        p.execute(m.Ax, x, y)
+        q.execute(m.Ax, x, y2)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2) and not torch.isnan(y).any()
+        # the one-shot symbol (mi355_spmv_auto_*), twice: the second call finds the kept plan under the AUTO key
+        y3 = torch.full((m.n_rows,), float("nan"), device=DEV)
+        sp.spmv("auto", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax, x, y3)
+        sp.spmv("hip_auto", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax, x, y3)
+        assert torch.equal(y3, y2)
+        assert_parity(oracle, m.Ap.cpu().numpy(), m.Aj.cpu().numpy(), m.Ax.cpu().numpy(), x.cpu().numpy(), y.cpu().numpy())
+        p.destroy(); q.destroy()
+    # integer values: merge, the only kind that has them
+    rng = np.random.RandomState(4)
+    Ap, Aj, _ = random_csr(rng, 3001, 500, 12, np.int32, np.float32)
+    Ax = rng.randint(-5, 6, size=int(Ap[-1])).astype(np.int32)
+    xi = rng.randint(-5, 6, size=500).astype(np.int32)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    p = sp.Plan("auto", 3001, 500, int(Ap[-1]), d(Ap), d(Aj), torch.int32)
+    assert sp.capi.KIND_NAMES[p.info()["kind"]] == "merge"
+    yi = torch.zeros(3001, dtype=torch.int32, device=DEV)
+    p.execute(d(Ax), d(xi), yi)
+    torch.cuda.synchronize()
+    assert np.array_equal(yi.cpu().numpy(), oracle.spmv_genl_serial(0, Ap, Aj, Ax, xi))
+    # a row block cannot be AUTO (its kind is the whole matrix's)
+    with pytest.raises(RuntimeError):
+        sp.Plan.block("auto", None, 0, 0, 1, 0, 3001, 500, int(Ap[-1]), d(Ap), d(Aj), torch.float32)

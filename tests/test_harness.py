@@ -58,7 +58,7 @@ def test_malformed_entry_terminates_with_the_reference_message(exe, tmp_path):
 @pytest.mark.parametrize("extra", [[], ["--dtype", "f64"], ["--offset", "64"], ["--dtype", "f64", "--offset", "64"]])
 def test_tables_match_the_reference_format(exe, extra):
     path = os.path.join(GOLD, "c1_1138_bus_standin.mtx")
-    kinds = ["hip_vector", "hip_merge", "hip_light", "hip_functor"]
+    kinds = ["hip_vector", "hip_merge", "hip_light", "hip_auto", "hip_functor"]
     r = run(exe, path, *kinds, "--iters", "20", *extra)
     assert r.returncode == 0, r.stderr
     out = r.stdout
