@@ -62,6 +62,7 @@ static void parse_knobs(Knobs& k) {
     geti("MI355_MERGE_SEARCH_LANES", k.merge_search_lanes);
     geti("MI355_MERGE_FUSED", k.merge_fused);
     geti("MI355_MERGE_WIDE_WINDOW", k.merge_wide_window);
+    geti("MI355_MERGE_SEGMENTS", k.merge_segments);
     geti("MI355_SPMV_PLAN_CACHE", k.plan_cache);
     geti("MI355_MERGE_ROWS", k.merge_rows);
     geti("MI355_DIST_TRIALS", k.dist_trials);
@@ -98,13 +99,14 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(int32_t n_rows, const off
     // out[2 + 32 t + i]: (column - row) at 32 positions spread over row t's nonzeros (LLONG_MAX = none);
     // out[2 + 32 * 256], out[3 + 32 * 256]: shortest / longest of the 256 rows
     __shared__ long long s_lo[kBlock / kWave], s_hi[kBlock / kWave], s_lmin[kBlock / kWave], s_lmax[kBlock / kWave];
+    __shared__ int s_short;
     const int tid = threadIdx.x;
-    long long lo = LLONG_MAX, hi = LLONG_MIN, lmin = LLONG_MAX, lmax = 0;
+    long long lo = LLONG_MAX, hi = LLONG_MIN, lmin = LLONG_MAX, lmax = 0, mine = 0;
     for (int i = 0; i < kProbePerRow; ++i) out[2 + tid * kProbePerRow + i] = LLONG_MAX;
     if (n_rows > 0) {
         const int64_t r = (int64_t(n_rows - 1) * tid) / (kBlock - 1);
         const off_t s = Ap[r], e = Ap[r + 1];
-        lmin = lmax = (long long)(e - s);
+        lmin = lmax = mine = (long long)(e - s);
         if (e > s) {
             const long long first = Aj[s], last = Aj[e - 1];
             lo = min(first, last) - r;
@@ -142,7 +144,23 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(int32_t n_rows, const off
         out[1] = hi;
         out[2 + kBlock * kProbePerRow] = lmin;
         out[3 + kBlock * kProbePerRow] = lmax;
+        s_lmax[0] = lmax;
+        s_short = 0;
     }
+    // how many of the sampled rows fill less than three quarters of the step (8, 16, 32, 64 or 128 nonzeros: the widths
+    // a vector of lanes covers at once) that the longest of them needs: a stencil's boundary rows are a few per cent
+    // of the sample, a matrix of VARYING row lengths half of it (merge_path.hip, merge_rows_wanted)
+    __syncthreads();
+    {
+        const long long longest = s_lmax[0];
+        long long step = 8;
+        while (step < longest && step < 128) step *= 2;
+        const bool is_short = n_rows > 0 && mine * 4 < step * 3;
+        const int n = __popcll(__ballot(is_short));
+        if ((tid & (kWave - 1)) == 0 && n) atomicAdd(&s_short, n);
+    }
+    __syncthreads();
+    if (tid == 0) out[4 + kBlock * kProbePerRow] = s_short;
 }
 
 // Device scratch of the plan-time kernels (probe samples, heaviest-chunk word): one allocation per device
@@ -174,9 +192,10 @@ int probe_structure(Plan& p) {
     p.n_seg = 0;
     if (p.n_rows <= 0 || p.nnz <= 0) return MI355_SPMV_OK;
     constexpr size_t NS = 2 + size_t(kBlock) * kProbePerRow;   // band + samples
-    constexpr size_t N = NS + 2;                                // + shortest / longest sampled row
+    constexpr size_t N = NS + 3;                                // + shortest / longest sampled row, + the count of short ones
     static_assert(size_t(kBlock) * kProbePerRow <= sizeof(p.probe_off) / sizeof(p.probe_off[0]), "probe buffer");
     p.probe_len_min = p.probe_len_max = 0;
+    p.probe_short_rows = 0;
     std::lock_guard<std::mutex> lock(g_analysis_mutex);
     long long* d_out = analysis_buffer();
     if (!d_out) { set_error("probe_structure: no device scratch"); return MI355_SPMV_ENOMEM; }
@@ -202,6 +221,7 @@ int probe_structure(Plan& p) {
             if (h[i] != LLONG_MAX) p.probe_off[p.probe_n++] = h[i];
         p.probe_len_min = h[NS];
         p.probe_len_max = h[NS + 1];
+        p.probe_short_rows = int(h[NS + 2]);
         p.probe_sorted = false;    // sorted on first use (cluster_bands): most plans never need the samples
     }
     delete[] h;

@@ -95,6 +95,7 @@ struct Knobs {
     int merge_fused = -1;      // MI355_MERGE_FUSED           0 = never the single-launch small-grid kernel, 1 = whenever legal
     int plan_cache = -1;       // MI355_SPMV_PLAN_CACHE       0 = the one-shot entry points make and destroy a plan per call
     int merge_wide_window = -1;// MI355_MERGE_WIDE_WINDOW     0 = fp64 keeps the 36 KB window budget (no second try with 56 KB)
+    int merge_segments = -1;   // MI355_MERGE_SEGMENTS        0 = a regular several-band matrix keeps the item walk (no segmented runs)
     int dist_exchange = 0;     // MI355_DIST_EXCHANGE         auto | bcast | sendrecv | allgather (MI355_DIST_EXCHANGE_*; auto = timed trial at create)
     int dist_trials = 0;       // MI355_DIST_TRIALS           exchanges timed per candidate by the auto pick (default 5)
     int dist_shared_device = 0;// MI355_DIST_SHARED_DEVICE    tests: 1 = a device may be listed twice (an emulated RCCL: several "GPUs" on one)
@@ -134,6 +135,7 @@ struct Plan {
     bool coords_valid;
     bool merge_rows;            // MERGE: regular matrix -> runs are summed row-parallel (merge_rows_kernel)
     int64_t probe_len_min, probe_len_max;   // shortest / longest of the probe's sampled rows (valid when probe_ok)
+    int probe_short_rows = 0;               // ... and how many of the 256 fill less than 3/4 of the step the longest needs
     int semiring;               // MERGE: MI355_SEMIRING_* (0 = plus-times)
     double alpha, beta;         // y = alpha * A x + beta * y (1, 0 by default)
     // structure probe (plan creation): band of (column - row) seen on sampled rows

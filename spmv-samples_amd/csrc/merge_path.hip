@@ -485,13 +485,19 @@ constexpr int kMergeRowsCap = 1984;    // rows per piece: bounds + results fit 1
 // TS > 0: the band is wider than any window (plan: shape_merge, mr_sweep_lanes) — a piece is then ONE group of rows of the
 // 1 024-thread workgroup, TS lanes per row and R rows per vector held in registers, and the window sweeps the band
 // (xwindow.hpp, chunk_rows_sweep: the CSR-vector kind's body for such bands; plain gathers ran the run at 1.6 TB/s).
-template <int BLOCK, int R, bool WINDOW, bool SEARCH, typename off_t, typename val_t, int TS = 0>
+// NSEG > 1: the columns sit in several far-apart bands (the 3-D stencil) — each band gets its own segment of the window,
+// staged per piece of the run (xwindow.hpp, stage_x_segments: the CSR-vector kind's multi-band plan).
+template <int NSEG> struct SegmentArg { static const SegmentPlan& pick(const SegmentPlan& s, const struct NoSegments&) { return s; } };
+struct NoSegments {};   // (the one-window variants take no segment list: 68 bytes of kernel arguments cost the sweep variants their last scalar registers)
+template <> struct SegmentArg<1> { static const NoSegments& pick(const SegmentPlan&, const NoSegments& n) { return n; } };
+template <int BLOCK, int R, bool WINDOW, bool SEARCH, typename off_t, typename val_t, int TS = 0, int NSEG = 1>
 __global__ __launch_bounds__(BLOCK, (BLOCK >= kWideBlock ? 4 : 3)) void merge_rows_kernel(
     int32_t n_rows, int32_t n_cols, int64_t nnz_begin, int64_t nnz, const off_t* __restrict__ Ap,
     const int32_t* __restrict__ Aj_arg, const val_t* __restrict__ Ax_arg, const val_t* __restrict__ x_arg,
     val_t* __restrict__ y_arg, int64_t tile_items, const int32_t* __restrict__ run_row, const int64_t* __restrict__ run_nnz,
     int32_t* __restrict__ carry_row, val_t* __restrict__ carry_val,
-    int64_t n_tiles, int32_t tiles_per_super, int32_t window_cap, BandHint hint, val_t alpha, val_t beta, int32_t piece_rows) {
+    int64_t n_tiles, int32_t tiles_per_super, int32_t window_cap, BandHint hint, val_t alpha, val_t beta, int32_t piece_rows,
+    typename std::conditional<(NSEG > 1), SegmentPlan, NoSegments>::type segs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // window | bounds | y | flags
     __shared__ int s_red[2];
     __shared__ int64_t s_diag[4];            // (row, nnz) of the run's first and last diagonal
@@ -564,15 +570,20 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= kWideBlock ? 4 : 3)) void merge_ro
             __syncthreads();
             continue;
         }
-        auto first_last = [&](int64_t r, int& fc, int& lc) {
-            const int32_t s = scr.s_b[r - rb], e = scr.s_b[r - rb + 1];
-            if (e <= s) return false;
-            fc = Aj_c[s];
-            lc = Aj_c[e - 1];
-            return true;
-        };
-        auto stage = [&] { return stage_x_window<val_t>(rb, re, n_cols, first_last, x, scr.s_x, window_cap, s_red, hint); };
-        chunk_rows_any<BLOCK, 2, R, WINDOW, true, val_t, decltype(stage)&, true>(rb, re, nnz_c, Aj_c, Ax_c, x, y, stage, scr);
+        if constexpr (NSEG > 1) {
+            auto stage = [&] { return stage_x_segments<val_t>(rb, re, n_cols, x, scr.s_x, window_cap, segs); };
+            chunk_rows_any<BLOCK, 2, R, true, true, val_t, decltype(stage)&, true>(rb, re, nnz_c, Aj_c, Ax_c, x, y, stage, scr);
+        } else {
+            auto first_last = [&](int64_t r, int& fc, int& lc) {
+                const int32_t s = scr.s_b[r - rb], e = scr.s_b[r - rb + 1];
+                if (e <= s) return false;
+                fc = Aj_c[s];
+                lc = Aj_c[e - 1];
+                return true;
+            };
+            auto stage = [&] { return stage_x_window<val_t>(rb, re, n_cols, first_last, x, scr.s_x, window_cap, s_red, hint); };
+            chunk_rows_any<BLOCK, 2, R, WINDOW, true, val_t, decltype(stage)&, true>(rb, re, nnz_c, Aj_c, Ax_c, x, y, stage, scr);
+        }
         __syncthreads();
         if (pe == n_all && n_all > n_store_all) carry = uniform_val(scr.s_y[rows - 1]);   // (one LDS word: scalar register)
         __syncthreads();                                                       // ... read before the next piece refills it
@@ -630,8 +641,10 @@ static bool merge_search_in_kernel(const Plan& p) {
     if (p.knob.merge_rows >= 0) return p.knob.merge_rows != 0;
     if (!p.probe_ok || p.n_rows <= 0 || p.val_type == MI355_VAL_I32) return false;
     if (p.tiles_per_super * p.tile_items < 16384) return false;
+    // (... or all but an eighth of them do: the boundary rows of a stencil — the nlpkkt stand-in's 27-point rows are
+    // 18, 12 or 8 long on the faces, edges and corners of its box — cost their vectors a few idle lanes, nothing more)
     for (const int64_t step : {8, 16, 32, 64, 128})
-        if (p.probe_len_max <= step && p.probe_len_min * 4 >= step * 3) return true;
+        if (p.probe_len_max <= step && (p.probe_len_min * 4 >= step * 3 || p.probe_short_rows * 8 <= kBlock)) return true;
     return false;
 }
 
@@ -658,6 +671,7 @@ void shape_merge(Plan& p) {
     // a window of x only pays when a run is long enough to amortise staging it, and
     // when the band the probe saw (plus the rows of a run) fits
     bool several_bands = false;
+    int segment_piece = 0;             // rows per piece of a row-parallel run with one window segment per band (0: not that plan)
     {
         const int64_t mean1 = 1 + (p.n_rows > 0 ? (p.nnz - p.nnz_begin) / p.n_rows : 0);
         const int64_t rows_per_run = tps * p.tile_items / mean1 + 1;
@@ -670,8 +684,32 @@ void shape_merge(Plan& p) {
             p.window_elems = pick_window_elems(p, rows_per_run);
             if (p.window_elems == 0 || p.n_seg >= 2) p.window_bytes = 0;
         }
-        several_bands = p.n_seg >= 2;
-        if (p.n_seg >= 2) { p.window_elems = 0; p.n_seg = 0; }   // several bands: this kind keeps to global gathers
+        // Several far-apart bands (the 3-D stencil).  A REGULAR matrix of that kind takes row-parallel runs with a segment
+        // of the window per band, staged per piece of a run — the CSR-vector kind's multi-band plan: the piece is as many
+        // rows as the bands leave room for, a run is one piece.  (Round 2 had this at 681 us against the item walk's 727
+        // on the C4 stand-in, with spilling kernels, and dropped it; the chunk body of round 3 fits its registers.)
+        // MI355_MERGE_SEGMENTS=0 keeps the item walk on plain gathers, as every other several-band matrix does.
+        if (p.n_seg >= 2 && p.block_threads == kBlock && p.knob.merge_segments != 0 && p.knob.merge_tps <= 0 &&
+            p.knob.window < 0 && merge_rows_wanted(p)) {
+            int64_t piece = segment_rows_fit(p);
+            if (piece > kMergeRowsCap) piece = kMergeRowsCap;
+            piece &= ~int64_t(3);
+            int64_t t2 = piece * mean1 / p.tile_items;
+            if (t2 > kMergeSuperItems / p.tile_items) t2 = kMergeSuperItems / p.tile_items;
+            const int64_t n_super = t2 >= 1 ? (p.n_tiles + t2 - 1) / t2 : 0;
+            if (piece >= 256 && t2 >= 1 && n_super >= int64_t(kCus) * 2) {
+                int64_t need = 0;                         // (LDS is occupancy: what the bands need with that many rows)
+                for (int i = 0; i < p.n_seg; ++i) need += p.seg_hi[i] - p.seg_lo[i] + 1 + 4 + piece;
+                need = (need + 3) & ~int64_t(3);
+                if (need < p.window_elems) p.window_elems = int(need);
+                p.tiles_per_super = t2;
+                p.n_super = n_super;
+                p.grid_blocks = n_super;
+                segment_piece = int(piece);
+            }
+        }
+        several_bands = p.n_seg >= 2 && segment_piece == 0;
+        if (several_bands) { p.window_elems = 0; p.n_seg = 0; }   // several bands: the item walk keeps to global gathers
     }
     p.n_kernels = (p.n_super > 1 ? 2 : 1) + ((merge_search_in_kernel(p) && p.block_threads == kBlock) ? 0 : 1);
     // (a matrix whose columns sit in several far-apart bands — the 3-D stencil — keeps the item walk: row-parallel runs
@@ -679,11 +717,12 @@ void shape_merge(Plan& p) {
     // 681 against 727 on one box, with four spilling kernels: not kept)
     p.merge_rows = p.block_threads == kBlock && !several_bands && merge_rows_wanted(p);
     p.mr_block = kBlock;
-    p.mr_piece_rows = kMergeRowsCap;
+    p.mr_piece_rows = segment_piece > 0 ? segment_piece : kMergeRowsCap;
+    if (segment_piece > 0 && !p.merge_rows) { p.window_elems = 0; p.n_seg = 0; }   // (cannot happen: merge_rows_wanted held above)
     // The band does not fit the window of a 256-thread workgroup (fp64 on the S32-band shape: 8 193 columns + the rows of a run):
     // two workgroups of 512 threads per CU may take ~78 KB each, as the CSR-vector kind's wide plan does; the run is then
     // as long as the rows the band leaves room for, and walked in one piece.
-    if (p.merge_rows && p.knob.merge_wide_window != 0 && p.knob.window < 0 && p.knob.merge_tps <= 0 && p.probe_ok &&
+    if (p.merge_rows && segment_piece == 0 && p.knob.merge_wide_window != 0 && p.knob.window < 0 && p.knob.merge_tps <= 0 && p.probe_ok &&
         !(p.window_elems > 0 && p.window_from_band)) {
         const int64_t vb = p.val_type == MI355_VAL_F64 ? 8 : 4;
         const int64_t band = p.band_hi - p.band_lo + 1;
@@ -804,15 +843,21 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
                 p.coords_valid = false;       // (the arrays now hold RUN boundaries, not tile coordinates)
             }
             // (rows a vector keeps in flight: the 512-thread kernel is held to 128 VGPRs, which the fp32 body with 4 rows exceeds)
-#define MI355_MERGE_ROWS_LAUNCH(BLOCK_, WIN_, SEARCH_)                                                             \
+            SegmentPlan segs;
+            segs.n = p.n_seg;
+            for (int i = 0; i < kMaxSegments; ++i) { segs.lo[i] = p.seg_lo[i]; segs.hi[i] = p.seg_hi[i]; }
+            const NoSegments no_segs;
+#define MI355_MERGE_ROWS_LAUNCH_N(BLOCK_, WIN_, SEARCH_, NSEG_)                                                    \
     do {                                                                                                           \
-        constexpr int RR_ = BLOCK_ >= kWideBlock ? 2 : RR;                                                          \
-        if (const int st = allow_dynamic_lds((const void*)merge_rows_kernel<BLOCK_, RR_, WIN_, SEARCH_, off_t, val_t>, lds + 1024)) return st; \
-        hipLaunchKernelGGL((merge_rows_kernel<BLOCK_, RR_, WIN_, SEARCH_, off_t, val_t>), grid_r, dim3(BLOCK_), lds, s, p.n_rows, \
+        constexpr int RR_ = (BLOCK_ >= kWideBlock || NSEG_ > 1) ? 2 : RR;   /* (several bands: the fp32 body with 4 rows spills) */ \
+        const auto& segs_ = SegmentArg<NSEG_>::pick(segs, no_segs);                                                 \
+        if (const int st = allow_dynamic_lds((const void*)merge_rows_kernel<BLOCK_, RR_, WIN_, SEARCH_, off_t, val_t, 0, NSEG_>, lds + 1024)) return st; \
+        hipLaunchKernelGGL((merge_rows_kernel<BLOCK_, RR_, WIN_, SEARCH_, off_t, val_t, 0, NSEG_>), grid_r, dim3(BLOCK_), lds, s, p.n_rows, \
                            p.n_cols, p.nnz_begin, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_items, p.tile_row, p.tile_nnz,   \
                            p.carry_row, static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super,    \
-                           capw, hint_r, (val_t)p.alpha, (val_t)p.beta, (int32_t)p.mr_piece_rows);                  \
+                           capw, hint_r, (val_t)p.alpha, (val_t)p.beta, (int32_t)p.mr_piece_rows, segs_);           \
     } while (0)
+#define MI355_MERGE_ROWS_LAUNCH(BLOCK_, WIN_, SEARCH_) MI355_MERGE_ROWS_LAUNCH_N(BLOCK_, WIN_, SEARCH_, 1)
             if (p.mr_sweep_lanes > 0 && capw > 0) {           // the window sweeps the band: one group of rows per piece
                 constexpr int RS = sizeof(val_t) == 4 ? 8 : kSweepRows;
                 const BandHint hint_s{p.band_lo, p.band_hi, true};
@@ -826,7 +871,7 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
         hipLaunchKernelGGL((merge_rows_kernel<kHugeBlock, RS, true, SEARCH_, off_t, val_t, TS_>), grid_r, dim3(kHugeBlock), lds, s, p.n_rows, \
                            p.n_cols, p.nnz_begin, p.nnz, Ap, p.Aj, Ax, x, y, p.tile_items, p.tile_row, p.tile_nnz,   \
                            p.carry_row, static_cast<val_t*>(p.carry_val), p.n_tiles, (int32_t)p.tiles_per_super,    \
-                           capw, hint_s, (val_t)p.alpha, (val_t)p.beta, (int32_t)p.mr_piece_rows);                  \
+                           capw, hint_s, (val_t)p.alpha, (val_t)p.beta, (int32_t)p.mr_piece_rows, no_segs);         \
     } while (0)
                 switch (p.mr_sweep_lanes) {
                     case 4:  if (in_kernel) MI355_MERGE_SWEEP_LAUNCH(4, true); else MI355_MERGE_SWEEP_LAUNCH(4, false); break;
@@ -843,9 +888,13 @@ int launch_merge(Plan& p, const off_t* Ap, const mat_t* Ax, const val_t* x, val_
             else if (p.mr_block == kWideBlock && capw > 0) {
                 if (in_kernel) MI355_MERGE_ROWS_LAUNCH(kWideBlock, true, true); else MI355_MERGE_ROWS_LAUNCH(kWideBlock, true, false);
             }
+            else if (capw > 0 && p.n_seg >= 2) {                   // several bands: a segment of the window each
+                if (in_kernel) MI355_MERGE_ROWS_LAUNCH_N(kBlock, true, true, kMaxSegments); else MI355_MERGE_ROWS_LAUNCH_N(kBlock, true, false, kMaxSegments);
+            }
             else if (capw > 0) { if (in_kernel) MI355_MERGE_ROWS_LAUNCH(kBlock, true, true); else MI355_MERGE_ROWS_LAUNCH(kBlock, true, false); }
             else { if (in_kernel) MI355_MERGE_ROWS_LAUNCH(kBlock, false, true); else MI355_MERGE_ROWS_LAUNCH(kBlock, false, false); }
 #undef MI355_MERGE_ROWS_LAUNCH
+#undef MI355_MERGE_ROWS_LAUNCH_N
             MI355_HIP_TRY(hipGetLastError());
             if (p.n_super > 1) {
                 const unsigned g = unsigned((p.n_super + kBlock - 1) / kBlock);

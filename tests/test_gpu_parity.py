@@ -1182,3 +1182,36 @@ def test_auto_kind_picks_merge_on_skewed_rows_and_vector_otherwise(sp, oracle):
     # a row block cannot be AUTO (its kind is the whole matrix's)
     with pytest.raises(RuntimeError):
         sp.Plan.block("auto", None, 0, 0, 1, 0, 3001, 500, int(Ap[-1]), d(Ap), d(Aj), torch.float32)
+
+
+@pytest.mark.parametrize("off,val", [("i64", "f64"), ("i32", "f32")])
+def test_merge_runs_on_a_stencil_stage_a_window_segment_per_band(sp, oracle, off, val):
+    """A 27-point stencil on a 90^3 box: three far-apart bands of columns and boundary rows of 18 / 12 / 8 nonzeros among
+    the 27s.  The merge kind takes row-parallel runs with one segment of the window per band (shape_merge; the probe's
+    count of short rows lets the few boundary rows through) — every row within the bound of SURVEY §8(c), the rows that
+    straddle runs included (their partial sums meet in the fix-up)."""
+    tv = {"f32": torch.float32, "f64": torch.float64}[val]
+    to = {"i32": torch.int32, "i64": torch.int64}[off]
+    m = sp.synth.stencil27(90, 90, 90, 4, DEV, val_dtype=tv, off_dtype=to)
+    x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, DEV)
+    p = sp.Plan("merge", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype)
+    info = p.info()
+    if not any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB"):   # (no forced code path)
+        assert info["main_kernel"] == "merge_rows_kernel" and info["window_segments"] == 3, info
+    y = torch.full((m.n_rows,), float("nan"), dtype=m.Ax.dtype, device=DEV)
+    p.execute(m.Ax, x, y)
+    p.execute(m.Ax, x, y)
+    torch.cuda.synchronize()
+    Ap, Aj, Ax, xh = m.Ap.cpu().numpy(), m.Aj.cpu().numpy(), m.Ax.cpu().numpy(), x.cpu().numpy()
+    assert_parity(oracle, Ap, Aj, Ax, xh, y.cpu().numpy())
+    lens = np.diff(Ap.astype(np.int64))
+    assert lens.max() == 27 and lens.min() == 8
+    # alpha / beta ride along the same kernels
+    p.set_alpha_beta(0.5, 2.0)
+    y2 = torch.ones(m.n_rows, dtype=m.Ax.dtype, device=DEV)
+    p.execute(m.Ax, x, y2)
+    torch.cuda.synchronize()
+    want = 0.5 * y.cpu().numpy().astype(np.float64) + 2.0
+    tol = 1e-5 if val == "f32" else 1e-13
+    assert np.allclose(y2.cpu().numpy(), want, rtol=tol, atol=tol * 32)
+    p.destroy()
