@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <hip/hiprtc.h>   // types and prototypes only; no symbol of it is linked
 
+#include <deque>
 #include <mutex>
 #include <new>
 #include <string>
@@ -106,7 +107,7 @@ struct mi355_spmv_functor {
     int off_type = MI355_OFF_I32;
     std::vector<char> code;
     std::mutex mutex;                                // guards `loaded`
-    std::vector<Loaded> loaded;
+    std::deque<Loaded> loaded;                       // (a deque: references handed out stay valid as devices are added)
 };
 
 namespace {
@@ -142,7 +143,6 @@ int load_on_current_device(mi355_spmv_functor* f, const Loaded** out) {
         set_error("functor_spmv: hipModuleGetFunction -> %s", hipGetErrorString(e));
         return MI355_SPMV_EHIP;
     }
-    f->loaded.reserve(16);                           // (pointers into it are handed out: never reallocated below 16 devices)
     f->loaded.push_back(l);
     *out = &f->loaded.back();
     return MI355_SPMV_OK;
