@@ -530,18 +530,23 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= kWideBlock ? 4 : 3)) void merge_ro
         }
         __syncthreads();
     }
-    const int64_t row_lo = uniform_i64(s_diag[0]), y_first = uniform_i64(s_diag[1]);
-    const int64_t row_last = uniform_i64(s_diag[2]), y_last = uniform_i64(s_diag[3]);
-    // rows [row_lo, row_last) END in this run; row_last (if it exists) is open at its end
-    const int64_t n_store_all = row_last - row_lo;
-    const int64_t n_all = n_store_all + (row_last < n_rows ? 1 : 0);
-    const int64_t base = y_first & ~int64_t(3);
-    const int64_t left = nnz - base;
-    const int32_t nnz_c = int32_t(left < kRel32Limit ? left : kRel32Limit);
+    // rows [row_lo, row_last) END in this run; row_last (if it exists) is open at its end.  The four coordinates stay in
+    // LDS and are read again by every piece (scalar loads): held in scalar registers across the pieces they were what
+    // pushed the eight-row sweeping variants past their register budget.  Row counts of a run fit 32 bits.
+    int n_store_all, n_all;
+    {
+        const int64_t row_lo0 = uniform_i64(s_diag[0]), row_last0 = uniform_i64(s_diag[2]);
+        n_store_all = int(row_last0 - row_lo0);
+        n_all = n_store_all + (row_last0 < n_rows ? 1 : 0);
+    }
     val_t carry = val_t(0);
-    for (int64_t pb = 0; pb < n_all; pb += piece_rows) {             // (uniform; one piece unless the run holds more rows than the layout)
-        const int64_t pe = min(pb + int64_t(piece_rows), n_all);
-        const int rows = int(pe - pb);
+    for (int pb = 0; pb < n_all; pb += piece_rows) {                 // (uniform; one piece unless the run holds more rows than the layout)
+        const int pe = min(pb + piece_rows, n_all);
+        const int rows = pe - pb;
+        const int64_t row_lo = uniform_i64(s_diag[0]), y_first = uniform_i64(s_diag[1]), y_last = uniform_i64(s_diag[3]);
+        const int64_t base = y_first & ~int64_t(3);
+        const int64_t left = nnz - base;
+        const int32_t nnz_c = int32_t(left < kRel32Limit ? left : kRel32Limit);
         // opaque copies of the operand pointers, once per piece (see light_rows.hip: keeps per-thread addresses from
         // being hoisted out of this loop and spilled)
         int zero = 0;
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= kWideBlock ? 4 : 3)) void merge_ro
             scr.s_b[i] = int32_t(b - base);
         }
         for (int i = t2; i < rows / 32 + 1; i += BLOCK) scr.long_map[i] = 0u;
-        scr.store_rows = int(min(pe, n_store_all) - pb);              // the open row's partial stays in s_y
+        scr.store_rows = min(pe, n_store_all) - pb;                   // the open row's partial stays in s_y
         __syncthreads();
         const int64_t rb = row_lo + pb, re = row_lo + pe;
         if constexpr (TS > 0) {
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= kWideBlock ? 4 : 3)) void merge_ro
         __syncthreads();                                                       // ... read before the next piece refills it
     }
     if (tid == 0) {
-        carry_row[sup] = int32_t(row_last);       // == n_rows: no row is open (the fix-up skips it)
+        carry_row[sup] = int32_t(s_diag[2]);      // the run's last row; == n_rows: no row is open (the fix-up skips it)
         carry_val[sup] = carry;
     }
 }
