@@ -652,12 +652,13 @@ static int window_budget(const Plan& p, int block_threads, int64_t rows) {
 void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide, bool allow_huge) {
     if (p.val_type == MI355_VAL_F32 && p.lanes_per_row >= 16 && R > 2) R = 2;   // (the kernels' rule: launch_*_window, wide_r)
     int64_t rows_before_rounding = 0;        // of the last shape(): the chunk before it was shrunk to whole rounds
-    auto shape = [&](int block_threads, int64_t nnz_per_chunk) {
+    auto shape = [&](int block_threads, int64_t nnz_per_chunk, int64_t rows_wanted = 0) {
         p.block_threads = block_threads;
         const int64_t pass = int64_t(block_threads / p.lanes_per_row) * R;
         int64_t rows = pick_rows_per_chunk(p.nnz, p.n_rows, p.lanes_per_row, R, block_threads, nnz_per_chunk,
                                            workgroups_per_cu_by_registers(p));
         if (div > 1) rows = (rows / div + pass - 1) / pass * pass;
+        if (rows_wanted > 0) rows = std::min<int64_t>((rows_wanted + 3) & ~int64_t(3), kMaxChunkRows);
         if (p.knob.rows_per_chunk > 0) {
             int64_t r = p.knob.rows_per_chunk;
             r = (r + pass - 1) / pass * pass;
@@ -716,11 +717,22 @@ void shape_chunks(Plan& p, int R, int64_t div, bool allow_wide, bool allow_huge)
         // are long (16+ lanes per row: the R = 2 bodies): the same rows by half as many workgroups, i.e. half the
         // prologues (bounds, window, barriers) in a kernel that is nothing but its prologue and four groups of rows.
         // cant stand-in: 10.7-10.8 us against 10.9-11.2 with 976 workgroups of 256 (rounds 2 and 3, three boxes).
-        {
+        // ... and whatever the row length when every workgroup still gets TWO groups of rows or more to pipeline: two
+        // workgroups of 512 per CU — or, where that leaves them a single group each, one per CU with twice the rows.
+        // S32-band shape, fp32, T = 8 (us, rule / the 256-thread plan with ~3 workgroups per CU it replaces;
+        // scripts/probes/mid_size_knobs.sh): 2^17 rows 10.6 / 11.6, 2^18 15.9 / 19.0, 2^19 27.4 / 29.2 — the
+        // mid-size matrices (35-140 MB) where a kernel is one round of the chip.
+        if (!force && p.knob.rows_per_chunk <= 0 && div <= 1 && p.window_elems > 0 && p.n_seg < 2 && p.window_from_band) {
+            const int64_t pass = int64_t(kWideBlock / p.lanes_per_row) * R;
             const int64_t n_chunks = p.rows_per_chunk > 0 ? (int64_t(p.n_rows) + p.rows_per_chunk - 1) / p.rows_per_chunk : 0;
-            if (!force && p.lanes_per_row >= 16 && p.window_elems > 0 && p.n_seg < 2 && p.window_from_band &&
-                n_chunks >= kCus && n_chunks <= int64_t(kCus) * 2)
-                return;
+            if (n_chunks >= kCus && n_chunks <= int64_t(kCus) * 2) {
+                if (p.lanes_per_row >= 16 || p.rows_per_chunk >= 2 * pass) return;
+                const int64_t twice = (int64_t(p.n_rows) + kCus - 1) / kCus;
+                if (twice >= 2 * pass && twice <= kMaxChunkRows) {
+                    shape(kWideBlock, 65536, twice);
+                    if (p.window_elems > 0 && p.n_seg < 2 && p.window_from_band) return;
+                }
+            }
         }
     }
     shape(kBlock, 32768);
