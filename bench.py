@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--band-half-width", type=int, default=4096,
                     help="s32-band: columns within +-this of the diagonal (4096 = the north-star target; wider bands "
                          "exercise the 1 024-thread and the sweeping-window plans)")
+    ap.add_argument("--nnz-per-row", type=int, default=32,
+                    help="nonzeros per row of the s32 workloads (32 = the north-star target; other lengths for plan studies)")
     ap.add_argument("--s32-offsets", choices=("i32", "i64"), default="i32", help="offset type of the s32 workloads")
     ap.add_argument("--s32-values", choices=("f32", "f64"), default="f32", help="value type of the s32 workloads")
     ap.add_argument("--reuse-structure", action="store_true",
@@ -207,13 +209,13 @@ def build_local(sp, args, rank, world, dev, sub_blocks):
         # blocks are statistically alike, every rank can write down everybody's cuts (32 nonzeros per row)
         n = 1 << args.rows_log2
         hw = args.band_half_width if args.workload == "s32-band" else None
-        m = sp.synth.banded_fixed(n, 32, hw, seed=1 + rank, device=dev, row_offset=rank * n, n_cols=world * n,
+        m = sp.synth.banded_fixed(n, args.nnz_per_row, hw, seed=1 + rank, device=dev, row_offset=rank * n, n_cols=world * n,
                                   val_dtype=torch.float64 if args.s32_values == "f64" else torch.float32,
                                   off_dtype=torch.int64 if args.s32_offsets == "i64" else torch.int32,
-                                  name=("S32-band" if hw == 4096 else "S32-band(+-%d)" % hw) if hw else "S32-rand")
+                                  name=(("S32-band" if hw == 4096 else "S32-band(+-%d)" % hw) if hw else "S32-rand") + ("" if args.nnz_per_row == 32 else "[%d per row]" % args.nnz_per_row))
         sub = [(n * s // sub_blocks) & ~3 for s in range(sub_blocks)]
         rows = [r * n + o for r in range(world) for o in sub] + [world * n]
-        return m, {"rows": rows, "chunks": None, "nnz": [32 * r for r in rows], "shape": None, "kind_shape": {}}
+        return m, {"rows": rows, "chunks": None, "nnz": [args.nnz_per_row * r for r in rows], "shape": None, "kind_shape": {}}
     full = load_matrix(sp, args, dev)
     if world == 1 and sub_blocks == 1:
         return full, {"rows": [0, full.n_rows], "chunks": None, "nnz": [0, full.nnz], "shape": None, "kind_shape": {}}
