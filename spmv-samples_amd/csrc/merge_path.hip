@@ -642,10 +642,14 @@ static bool merge_search_in_kernel(const Plan& p) {
 // 64: 205 / 245, 100: 229 / 242, 128: 195 / 237 — but 40: 262 / 256 (a step of 64 is 62 % full), and rows of VARYING length
 // lose at every mean (24 +- 6: 415 / 341, 64 +- 16: 479 / 381, 128 +- 32: 502 / 380): those keep the item walk, at
 // 4.8-5.5 TB/s.  MI355_MERGE_ROWS = 0 | 1 overrides.
+[[maybe_unused]] static bool merge_rows_regular(const Plan& p);
 [[maybe_unused]] static bool merge_rows_wanted(const Plan& p) {
     if (p.knob.merge_rows >= 0) return p.knob.merge_rows != 0;
+    if (p.tiles_per_super * p.tile_items < 16000) return false;      // (8 tiles of 2 044 items and up)
+    return merge_rows_regular(p);
+}
+[[maybe_unused]] static bool merge_rows_regular(const Plan& p) {
     if (!p.probe_ok || p.n_rows <= 0 || p.val_type == MI355_VAL_I32) return false;
-    if (p.tiles_per_super * p.tile_items < 16384) return false;
     // (... or all but an eighth of them do: the boundary rows of a stencil — the nlpkkt stand-in's 27-point rows are
     // 18, 12 or 8 long on the faces, edges and corners of its box — cost their vectors a few idle lanes, nothing more)
     for (const int64_t step : {8, 16, 32, 64, 128})
@@ -670,6 +674,14 @@ void shape_merge(Plan& p) {
     if (tps > cap) tps = cap;
     if (p.knob.merge_tps > 0) tps = p.knob.merge_tps;
     if (tps < 1) tps = 1;
+    // A REGULAR mid-size matrix (one to four runs of 8 tiles per CU) takes runs of 8 tiles rather than the two to seven
+    // the rule above gives it: 16 K items are what the row-parallel runs and their window of x need to pay
+    // (S32-band shape, us, before / after: 2^17 rows 20.5 / 19.4, 2^18 37.0 / 25.1, 2^19 47.7 / 41.3 — that one by the
+    // threshold in merge_rows_wanted alone).  Taken back below if no window placed from the band serves such a run.
+    const int64_t tps_small = tps;
+    const bool bumped = p.knob.merge_tps <= 0 && p.knob.merge_rows < 0 && tps < 8 && p.n_tiles >= 8 * int64_t(kCus) &&
+                        p.block_threads == kBlock && merge_rows_regular(p);
+    if (bumped) tps = 8;
     p.tiles_per_super = tps;
     p.n_super = (p.n_tiles + tps - 1) / tps;
     p.grid_blocks = p.n_super;
@@ -712,6 +724,15 @@ void shape_merge(Plan& p) {
                 p.grid_blocks = n_super;
                 segment_piece = int(piece);
             }
+        }
+        if (bumped && !(p.window_elems > 0 && p.n_seg < 2 && p.window_from_band)) {   // no window for runs of 8 tiles: the shorter runs
+            tps = tps_small;
+            p.tiles_per_super = tps;
+            p.n_super = (p.n_tiles + tps - 1) / tps;
+            p.grid_blocks = p.n_super;
+            p.window_bytes = 0;
+            p.window_elems = (tps * p.tile_items >= 8192) ? pick_window_elems(p, tps * p.tile_items / mean1 + 1) : 0;
+            segment_piece = 0;
         }
         several_bands = p.n_seg >= 2 && segment_piece == 0;
         if (several_bands) { p.window_elems = 0; p.n_seg = 0; }   // several bands: the item walk keeps to global gathers
