@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--offset", choices=("32", "64"), default="32", help="offset width of --mtx")
     ap.add_argument("--kind", default="auto", choices=("auto",) + KINDS)
     ap.add_argument("--rows-log2", type=int, default=22, help="rows per GPU of the s32 workloads (2^k)")
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU of the s32 workloads when not a power of two (overrides --rows-log2)")
     ap.add_argument("--band-half-width", type=int, default=4096,
                     help="s32-band: columns within +-this of the diagonal (4096 = the north-star target; wider bands "
                          "exercise the 1 024-thread and the sweeping-window plans)")
@@ -207,7 +208,7 @@ def build_local(sp, args, rank, world, dev, sub_blocks):
     if not args.mtx and args.workload in ("s32-band", "s32-rand"):
         # weak scaling: every rank generates its own 2^k rows of a banded matrix with world * 2^k rows; the
         # blocks are statistically alike, every rank can write down everybody's cuts (32 nonzeros per row)
-        n = 1 << args.rows_log2
+        n = args.rows if args.rows > 0 else 1 << args.rows_log2
         hw = args.band_half_width if args.workload == "s32-band" else None
         m = sp.synth.banded_fixed(n, args.nnz_per_row, hw, seed=1 + rank, device=dev, row_offset=rank * n, n_cols=world * n,
                                   val_dtype=torch.float64 if args.s32_values == "f64" else torch.float32,

@@ -1217,3 +1217,29 @@ def test_merge_runs_on_a_stencil_stage_a_window_segment_per_band(sp, oracle, off
     tol = 1e-5 if val == "f32" else 1e-13
     assert np.allclose(y2.cpu().numpy(), want, rtol=tol, atol=tol * 32)
     p.destroy()
+
+
+def test_mid_size_plans_are_one_round_of_two_workgroups_per_cu(sp, oracle):
+    """Plan rules measured in round 3 (profiles/r03_mid_size_*.txt), pinned: a regular banded matrix whose kernel is a
+    single round of the chip takes 512-thread workgroups, two per CU (or one with twice the rows), and its merge plan
+    runs of 8 tiles summed row-parallel.  Results: the oracle's bound, as everywhere."""
+    if any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB"):
+        pytest.skip("a forced code path decides the plan")
+    for lg, grid in ((17, 256), (18, 512)):
+        m = sp.synth.banded_fixed(1 << lg, 32, 4096, 1, DEV)
+        x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, DEV)
+        for kind in ("vector", "light", "merge"):
+            p = sp.Plan(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype)
+            info = p.info()
+            if kind == "merge":
+                assert info["main_kernel"] == "merge_rows_kernel" and info["window_elems"] > 0, info
+                assert info["grid_blocks"] == -(-info["n_tiles"] // 8), info
+            else:
+                assert info["block_threads"] == 512 and info["window_elems"] > 0, info
+                if kind == "vector":
+                    assert info["grid_blocks"] == grid, info
+            y = torch.full((m.n_rows,), float("nan"), device=DEV)
+            p.execute(m.Ax, x, y)
+            torch.cuda.synchronize()
+            assert_parity(oracle, m.Ap.cpu().numpy(), m.Aj.cpu().numpy(), m.Ax.cpu().numpy(), x.cpu().numpy(), y.cpu().numpy())
+            p.destroy()
