@@ -62,7 +62,10 @@ def rocsparse_direct(m, x, y_ours):
     return res
 
 for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["s32-band", "c2-cant", "c3-webgoogle"]):
-    m = sp.synth.workload(w, dev)
+    if w.startswith("s32-band@"):                      # the target's shape at 2^k rows (mid-size studies)
+        m = sp.synth.banded_fixed(1 << int(w.split("@")[1]), 32, 4096, 1, dev, name=w)
+    else:
+        m = sp.synth.workload(w, dev)
     with_torch = m.Ap.dtype == m.Aj.dtype and "--no-torch-sparse" not in sys.argv
     # (torch.sparse_csr_tensor does not validate index dtypes by default; int64 crow + int32 col indices faulted
     # inside the vendor path on MI355X, torch 2.10/ROCm 7.0: mixed dtypes are never handed to it)
