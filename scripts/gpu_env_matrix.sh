@@ -6,7 +6,7 @@
 mkdir -p gpurun_out
 rc=0
 skip=${1:-0}; i=0
-for env in "MI355_SPMV_WINDOW=1" "MI355_SPMV_WINDOW=0" "MI355_SPMV_WINDOW_FROM_BAND=0" "MI355_SPMV_SEGMENTS=0" "MI355_MERGE_TPS=1" "MI355_MERGE_TPS=5" "MI355_MERGE_SEARCH_LANES=1" "MI355_MERGE_SEARCH_LANES=4" "MI355_SPMV_BALANCE=1" "MI355_SPMV_BALANCE=0" "MI355_SPMV_BLOCK=512" "MI355_SPMV_BLOCK=256" "MI355_SPMV_PLAIN=1" "MI355_SPMV_LONG_STEPS=1" "MI355_MERGE_BLOCK=512" "MI355_SPMV_GIANT=0" "MI355_SPMV_SWEEP=1" "MI355_SPMV_SWEEP=0" "MI355_MERGE_ROWS=1" "MI355_MERGE_ROWS=0" "MI355_MERGE_FUSED=0" "MI355_MERGE_FUSED=1" "MI355_SPMV_REL32_LIMIT=5000" "MI355_SPMV_LANES=4" "MI355_SPMV_LANES=32" "MI355_MERGE_WIDE_WINDOW=0" "MI355_MERGE_SEGMENTS=0" "MI355_SPMV_GIANT_ROW=4096" "MI355_SPMV_PLAN_CACHE=0"; do
+for env in "MI355_SPMV_WINDOW=1" "MI355_SPMV_WINDOW=0" "MI355_SPMV_WINDOW_FROM_BAND=0" "MI355_SPMV_SEGMENTS=0" "MI355_MERGE_TPS=1" "MI355_MERGE_TPS=5" "MI355_MERGE_SEARCH_LANES=1" "MI355_MERGE_SEARCH_LANES=4" "MI355_SPMV_BALANCE=1" "MI355_SPMV_BALANCE=0" "MI355_SPMV_BLOCK=512" "MI355_SPMV_BLOCK=256" "MI355_SPMV_PLAIN=1" "MI355_SPMV_LONG_STEPS=1" "MI355_MERGE_BLOCK=512" "MI355_SPMV_GIANT=0" "MI355_SPMV_SWEEP=1" "MI355_SPMV_SWEEP=0" "MI355_MERGE_ROWS=1" "MI355_MERGE_ROWS=0" "MI355_MERGE_FUSED=0" "MI355_MERGE_FUSED=1" "MI355_SPMV_REL32_LIMIT=5000" "MI355_SPMV_LANES=4" "MI355_SPMV_LANES=32" "MI355_MERGE_WIDE_WINDOW=0" "MI355_MERGE_SEGMENTS=0" "MI355_SPMV_SMALL=1" "MI355_SPMV_GIANT_ROW=4096" "MI355_SPMV_PLAN_CACHE=0"; do
   i=$((i+1)); [ $i -le $skip ] && continue
   env $env timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/pt_env.log 2>&1
   r=$?

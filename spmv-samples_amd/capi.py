@@ -70,7 +70,7 @@ class PlanShape(C.Structure):
                 ("window_elems", C.c_int32), ("window_bytes", C.c_int32), ("window_from_band", C.c_int32),
                 ("window_segments", C.c_int32), ("probe_ok", C.c_int32), ("long_steps", C.c_int32),
                 ("band_lo", C.c_int64), ("band_hi", C.c_int64), ("seg_lo", C.c_int64 * 4), ("seg_hi", C.c_int64 * 4),
-                ("window_sweep", C.c_int32), ("reserved0", C.c_int32)]
+                ("window_sweep", C.c_int32), ("small_plain", C.c_int32)]
 
 
 class DistInfo(C.Structure):

@@ -54,6 +54,7 @@ static void parse_knobs(Knobs& k) {
     geti("MI355_SPMV_GIANT", k.giant);
     getl("MI355_SPMV_GIANT_ROW", k.giant_row);
     geti("MI355_SPMV_PLAIN", k.plain);
+    geti("MI355_SPMV_SMALL", k.small);
     getl("MI355_SPMV_REL32_LIMIT", k.rel32_limit);
     geti("MI355_LIGHT_BLOCKS_PER_CU", k.light_blocks_per_cu);
     geti("MI355_LIGHT_CHUNK_DIV", k.light_chunk_div);

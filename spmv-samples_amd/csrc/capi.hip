@@ -360,6 +360,7 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
         p.window_bytes = w->window_bytes;
         p.window_from_band = w->window_from_band != 0;
         p.sweep = w->window_sweep != 0;
+        p.small_plain = w->small_plain != 0 && kind == MI355_KIND_VECTOR;
         p.n_seg = w->window_segments >= 2 ? w->window_segments : 0;
         p.probe_ok = w->probe_ok != 0;
         // (column - row) bands were measured with whole-matrix row numbers; this plan's rows start at 0
@@ -392,6 +393,21 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
             const int st2 = find_giant_rows(p);  // balanced plans: rows too long for one workgroup (synchronises)
             if (st2 != MI355_SPMV_OK) { delete h; return st2; }
             if (p.n_giant > 0) p.n_kernels = 3;
+        }
+        // a small, regular matrix: the plain one-pass kernel (common.hpp, kSmallPlainNnz); two 4-byte elements per lane and row
+        if (kind == MI355_KIND_VECTOR && !blk && p.knob.small != 0 && p.knob.plain == 0 && !p.balanced && !p.sweep &&
+            p.n_giant == 0 && p.n_rows > 0 && (p.nnz - p.nnz_begin) <= kSmallPlainNnz) {
+            const int64_t mean = (p.nnz - p.nnz_begin) / p.n_rows;
+            int t = 2;
+            while (t < kWave && 2 * t < mean) t *= 2;
+            p.small_plain = true;
+            p.lanes_per_row = t;
+            p.block_threads = kBlock;
+            p.window_elems = 0;
+            p.n_seg = 0;
+            p.grid_blocks = (int64_t(p.n_rows) + kBlock / t - 1) / (kBlock / t);
+            p.n_kernels = 1;
+            snprintf(p.main_kernel, sizeof(p.main_kernel), "csr_vector_kernel");
         }
     }
     int st = plan_alloc_scratch(p);
@@ -473,6 +489,7 @@ int mi355_spmv_plan_get_shape(const mi355_spmv_plan* h, mi355_spmv_plan_shape* s
     sh->window_elems = p.window_elems; sh->window_bytes = p.window_bytes;
     sh->window_from_band = p.window_from_band ? 1 : 0;
     sh->window_sweep = p.sweep ? 1 : 0;
+    sh->small_plain = p.small_plain ? 1 : 0;
     sh->window_segments = p.n_seg >= 2 ? p.n_seg : (p.window_elems > 0 ? 1 : 0);
     sh->probe_ok = p.probe_ok ? 1 : 0;
     sh->long_steps = p.knob.long_steps;

@@ -41,6 +41,11 @@ inline int64_t sweep_window_cap(int64_t val_bytes, int64_t fixed_bytes) {
 inline int sweep_rows_for(int val_type, int lanes_per_row) {
     return (val_type == MI355_VAL_F32 && (kHugeBlock / lanes_per_row) * 8 <= 2048) ? 8 : kSweepRows;
 }
+// VECTOR below this many nonzeros: the chunked kernels are a prologue (bounds, window, barriers), a group or two of rows and
+// an epilogue — ~7.5 us however small the matrix — while the plain CSR-vector kernel (one pass, no LDS, no barrier) is done in
+// 2.7-6.5 us (kernel traces, S32-band shape: 2^12 rows 7.5 vs 2.7 us, 2^14 8.3 vs 3.2, 2^15 8.5 vs 4.3, 2^16 9.6 vs 6.2; even
+// at 2^17 rows = 4 M nonzeros, 11.0 both).  rocSPARSE's general kernel on the same boxes: 3.0 / 6.6 us at 2^14 / 2^16.
+constexpr int64_t kSmallPlainNnz = int64_t(3) << 20;
 constexpr int kXcds = 8;             // XCDs per MI355X, each with a private L2
 constexpr int kCus = 256;            // compute units per MI355X
 
@@ -85,6 +90,7 @@ struct Knobs {
     int giant = -1;            // MI355_SPMV_GIANT            0 = no giant-row slices
     int64_t giant_row = 0;     // MI355_SPMV_GIANT_ROW        nonzeros beyond which a row is giant (>= 4096)
     int plain = 0;             // MI355_SPMV_PLAIN            1 = the 4-byte-per-lane fallback kernels
+    int small = -1;            // MI355_SPMV_SMALL            0 = small matrices keep the chunked kernels too (VECTOR)
     int64_t rel32_limit = 0;   // MI355_SPMV_REL32_LIMIT      tests: nonzero span beyond which a chunk leaves the 32-bit path
     int light_blocks_per_cu = 0;   // MI355_LIGHT_BLOCKS_PER_CU
     int light_chunk_div = 0;   // MI355_LIGHT_CHUNK_DIV
@@ -182,6 +188,7 @@ struct Plan {
     unsigned long long* counters;  // LIGHT: kXcds shards, one 128-B line each
     bool light_dequeue_once;       // LIGHT, equal-row chunks: one workgroup and one dequeue per chunk (else by index)
     int n_kernels;
+    bool small_plain = false;   // VECTOR: a matrix small enough for the plain one-pass kernel to win (capi.hip, plan_create_impl)
     char main_kernel[64];
 };
 

@@ -311,7 +311,9 @@ int launch_vector(const Plan& p, const off_t* Ap, const val_t* Ax, const val_t* 
     // that passes an offset view gets the 4-byte-per-lane form instead.
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.Aj) | reinterpret_cast<uintptr_t>(Ax) |
                            reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
-    const bool force_plain = p.knob.plain != 0 && !p.is_block;   // tuning / tests (a block keeps the whole plan's order)
+    // (MI355_SPMV_PLAIN: tuning / tests — a block keeps the whole plan's order; small_plain: the plan's own choice for a
+    // small matrix, which a block inherits with its lanes per row: the same sums bit for bit)
+    const bool force_plain = (p.knob.plain != 0 && !p.is_block) || p.small_plain;
     if (aligned && p.nnz >= 4 && !force_plain) {
         const ApView view{Ap, sizeof(off_t) == 8 ? 1 : 0};
         if (p.sweep) return launch_vector_sweep<val_t>(p, view, Ax, x, y, s);

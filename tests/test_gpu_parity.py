@@ -363,7 +363,7 @@ def test_giant_rows_are_split_across_workgroups(sp, oracle, off):
     for kind in ("vector", "light"):
         p = sp.Plan(kind, n, n_cols, nnz, dAp, dAj, torch.float32)
         info = p.info()
-        if not any(k.startswith("MI355_SPMV_") for k in os.environ if k != "MI355_SPMV_LIB"):
+        if not any(k.startswith("MI355_SPMV_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL")):
             assert info["balanced_chunks"] == 1 and info["n_kernels"] == 3, info
         y = torch.empty(n, device=DEV)
         for rep in range(20):
@@ -403,7 +403,7 @@ def test_weight_cut_chunks_with_a_band_window_in_fp64_i64(sp, oracle, kind):
     dAp, dAj, dAx, dx = d(Ap), d(Aj), d(Ax), d(x)
     p = sp.Plan(kind, n, n, nnz, dAp, dAj, torch.float64)
     info = p.info()
-    if not any(k.startswith("MI355_SPMV_") for k in os.environ if k != "MI355_SPMV_LIB"):   # (no forced code path)
+    if not any(k.startswith("MI355_SPMV_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL")):   # (no forced code path)
         assert info["balanced_chunks"] == 1 and info["window_elems"] > 0, info
     y = torch.full((n,), float("nan"), dtype=torch.float64, device=DEV)
     p.execute(dAx, dx, y)
@@ -425,7 +425,7 @@ def test_band_too_wide_for_two_workgroups_takes_one_of_1024_threads(sp, oracle, 
     x = sp.synth.dense_vector(m.n_cols, dt, 10, DEV)
     p = sp.Plan(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, dt)
     info = p.info()
-    if not any(k.startswith("MI355_SPMV_") for k in os.environ if k != "MI355_SPMV_LIB"):   # (no forced code path)
+    if not any(k.startswith("MI355_SPMV_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL")):   # (no forced code path)
         assert info["block_threads"] == 1024 and info["window_elems"] * m.Ax.element_size() > 100 * 1024, info
     y = torch.full((n,), float("nan"), dtype=dt, device=DEV)
     p.execute(m.Ax, x, y)
@@ -435,7 +435,7 @@ def test_band_too_wide_for_two_workgroups_takes_one_of_1024_threads(sp, oracle, 
     assert_parity(oracle, Ap, Aj, Ax, x.cpu().numpy(), y.cpu().numpy())
     small = sp.synth.banded_fixed(100_000, 32, hw, seed=4, device=DEV, val_dtype=dt)
     p = sp.Plan(kind, small.n_rows, small.n_cols, small.nnz, small.Ap, small.Aj, dt)
-    assert p.info()["block_threads"] != 1024 or any(k.startswith("MI355_SPMV_") for k in os.environ if k != "MI355_SPMV_LIB")
+    assert p.info()["block_threads"] != 1024 or any(k.startswith("MI355_SPMV_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL"))
     p.destroy()
 
 
@@ -449,7 +449,7 @@ def test_wide_band_fp64_takes_more_than_64_kb_of_lds(sp, oracle, kind):
     x = sp.synth.dense_vector(m.n_cols, torch.float64, 9, DEV)
     p = sp.Plan(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, torch.float64)
     info = p.info()
-    if not any(k.startswith("MI355_SPMV_") for k in os.environ if k != "MI355_SPMV_LIB"):   # (no forced code path)
+    if not any(k.startswith("MI355_SPMV_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL")):   # (no forced code path)
         assert info["block_threads"] == 512 and info["window_elems"] * 8 > 64 * 1024, info
     y = torch.full((n,), float("nan"), dtype=torch.float64, device=DEV)
     p.execute(m.Ax, x, y)
@@ -496,7 +496,7 @@ def test_band_wider_than_any_window_is_swept(sp, oracle, off, val, kind):
     sweep_kernel = "csr_vector_sweep_kernel" if kind == "vector" else "light_rows_sweep_kernel"
     p = sp.Plan(kind, n, n, nnz, dAp, dAj, dAx.dtype)
     info = p.info()
-    forced = any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB")
+    forced = any(k.startswith("MI355_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL"))
     if not forced:
         assert info["main_kernel"] == sweep_kernel and info["block_threads"] == 1024, info
     y = torch.full((n,), float("nan"), dtype=dAx.dtype, device=DEV)
@@ -589,7 +589,7 @@ def test_merge_runs_sweep_a_band_wider_than_any_window(sp, oracle, off, val):
     dAp, dAj, dAx, dx = d(Ap.astype(NP[off])), d(Aj), d(Ax), d(x)
     p = sp.Plan("merge", n, n, nnz, dAp, dAj, dAx.dtype)
     info = p.info()
-    forced = any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB")
+    forced = any(k.startswith("MI355_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL"))
     if not forced:
         assert info["main_kernel"] == "merge_rows_kernel" and info["block_threads"] == 1024 and info["window_elems"] > 30_000 // (2 if val == "f64" else 1), info
     for _ in range(2):                                   # twice: the run boundaries / carries are rewritten by every execute
@@ -697,7 +697,7 @@ def test_kept_one_shot_plan_meets_a_row_beyond_every_giant_threshold(sp, oracle,
     # a fresh plan for the same arrays does cut the row into slices (more kernels per execute) and agrees
     sp.capi.cache_release()
     p = sp.Plan(kind, n, n, nnz, dAp, dAj, torch.float32)
-    if kind != "merge" and not any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB"):   # (no forced code path)
+    if kind != "merge" and not any(k.startswith("MI355_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL")):   # (no forced code path)
         assert p.info()["n_kernels"] == 3
     y2 = torch.full((n,), float("nan"), device=DEV)
     p.execute(dAx, dx, y2)
@@ -762,7 +762,7 @@ def test_merge_runs_take_a_wide_workgroup_when_the_band_needs_it(sp, oracle, off
     x = sp.synth.dense_vector(m.n_cols, dt, 8, DEV)
     p = sp.Plan("merge", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, dt)
     info = p.info()
-    if not any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB"):
+    if not any(k.startswith("MI355_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL")):
         assert info["main_kernel"] == "merge_rows_kernel" and info["block_threads"] == block and \
             info["window_elems"] * m.Ax.element_size() > 64 * 1024, info
     y = torch.full((n,), float("nan"), dtype=dt, device=DEV)
@@ -1109,7 +1109,7 @@ def test_merge_on_a_regular_matrix_takes_row_parallel_runs(sp, oracle):
     x = sp.synth.dense_vector(m.n_cols, torch.float32, 6, DEV)
     p = sp.Plan("merge", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, torch.float32)
     info = p.info()
-    if not any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB"):
+    if not any(k.startswith("MI355_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL")):
         assert info["main_kernel"] == "merge_rows_kernel", info
     y = torch.full((m.n_rows,), float("nan"), device=DEV)
     p.execute(m.Ax, x, y)
@@ -1152,7 +1152,7 @@ def test_auto_kind_picks_merge_on_skewed_rows_and_vector_otherwise(sp, oracle):
     for m, want in ((band, "vector"), (skew, "merge")):
         x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, DEV)
         p = sp.Plan("auto", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype)
-        if any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB"):   # (a forced code path may force the pick:
+        if any(k.startswith("MI355_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL")):   # (a forced code path may force the pick:
             want = sp.capi.KIND_NAMES[p.info()["kind"]]                                  #  MI355_SPMV_BALANCE=1 makes every matrix "skewed")
         assert sp.capi.KIND_NAMES[p.info()["kind"]] == want
         q = sp.Plan(want, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype)
@@ -1198,7 +1198,7 @@ def test_merge_runs_on_a_stencil_stage_a_window_segment_per_band(sp, oracle, off
     x = sp.synth.dense_vector(m.n_cols, m.Ax.dtype, 1, DEV)
     p = sp.Plan("merge", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype)
     info = p.info()
-    if not any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB"):   # (no forced code path)
+    if not any(k.startswith("MI355_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL")):   # (no forced code path)
         assert info["main_kernel"] == "merge_rows_kernel" and info["window_segments"] == 3, info
     y = torch.full((m.n_rows,), float("nan"), dtype=m.Ax.dtype, device=DEV)
     p.execute(m.Ax, x, y)
@@ -1223,7 +1223,7 @@ def test_mid_size_plans_are_one_round_of_two_workgroups_per_cu(sp, oracle):
     """Plan rules measured in round 3 (profiles/r03_mid_size_*.txt), pinned: a regular banded matrix whose kernel is a
     single round of the chip takes 512-thread workgroups, two per CU (or one with twice the rows), and its merge plan
     runs of 8 tiles summed row-parallel.  Results: the oracle's bound, as everywhere."""
-    if any(k.startswith("MI355_") for k in os.environ if k != "MI355_SPMV_LIB"):
+    if any(k.startswith("MI355_") for k in os.environ if k not in ("MI355_SPMV_LIB", "MI355_SPMV_SMALL")):
         pytest.skip("a forced code path decides the plan")
     for lg, grid in ((17, 256), (18, 512)):
         m = sp.synth.banded_fixed(1 << lg, 32, 4096, 1, DEV)
