@@ -398,8 +398,11 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
         if (kind == MI355_KIND_VECTOR && !blk && p.knob.small != 0 && p.knob.plain == 0 && !p.balanced && !p.sweep &&
             p.n_giant == 0 && p.n_rows > 0 && (p.nnz - p.nnz_begin) <= kSmallPlainNnz) {
             const int64_t mean = (p.nnz - p.nnz_begin) / p.n_rows;
+            // lanes per row: two 4-byte elements per lane and row up to 32 per row, four beyond (measured: 32 per row 16 lanes
+            // over 8 and 32; 64 per row 16 lanes over 32 and 64)
+            const int64_t per_lane = mean <= 32 ? 2 : 4;
             int t = 2;
-            while (t < kWave && 2 * t < mean) t *= 2;
+            while (t < kWave && per_lane * t < mean) t *= 2;
             p.small_plain = true;
             p.lanes_per_row = t;
             p.block_threads = kBlock;

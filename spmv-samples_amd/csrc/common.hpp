@@ -45,7 +45,8 @@ inline int sweep_rows_for(int val_type, int lanes_per_row) {
 // an epilogue — ~7.5 us however small the matrix — while the plain CSR-vector kernel (one pass, no LDS, no barrier) is done in
 // 2.7-6.5 us (kernel traces, S32-band shape: 2^12 rows 7.5 vs 2.7 us, 2^14 8.3 vs 3.2, 2^15 8.5 vs 4.3, 2^16 9.6 vs 6.2; even
 // at 2^17 rows = 4 M nonzeros, 11.0 both).  rocSPARSE's general kernel on the same boxes: 3.0 / 6.6 us at 2^14 / 2^16.
-constexpr int64_t kSmallPlainNnz = int64_t(3) << 20;
+// The cant stand-in (4.0 M nonzeros, 64 per row): 11.7 us chunked, 10.2 plain at 16 lanes per row (11.5 at 32, 13.7 at 64).
+constexpr int64_t kSmallPlainNnz = 4100000;
 constexpr int kXcds = 8;             // XCDs per MI355X, each with a private L2
 constexpr int kCus = 256;            // compute units per MI355X
 

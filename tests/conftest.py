@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
-# The product runs a SMALL regular matrix (VECTOR kind, up to 3 M nonzeros) on its plain one-pass kernel (capi.hip,
+# The product runs a SMALL regular matrix (VECTOR kind, up to 4.1 M nonzeros) on its plain one-pass kernel (capi.hip,
 # small_plain).  Most matrices of this suite are small on purpose — empty rows, one long row, ragged lengths — and are
 # there to put the CHUNKED kernels through those cases, so the suite switches that choice off for itself;
 # tests/test_gpu_small.py runs the same kinds of matrices through the product's default, and the forced-code-path

@@ -63,7 +63,7 @@ def test_a_skewed_or_big_matrix_keeps_the_chunked_kernels(sp, small_on):
     skew = sp.synth.rmat(14, 16, seed=5, device=DEV)                       # weight-cut chunks: not the plain kernel
     p = sp.Plan("vector", skew.n_rows, skew.n_cols, skew.nnz, skew.Ap, skew.Aj, skew.Ax.dtype)
     assert p.info()["main_kernel"] != "csr_vector_kernel"
-    big = sp.synth.banded_fixed(1 << 17, 32, 4096, 1, DEV)                 # 4 M nonzeros: above the threshold
+    big = sp.synth.banded_fixed(1 << 17, 32, 4096, 1, DEV)                 # 4.19 M nonzeros: above the threshold
     q = sp.Plan("vector", big.n_rows, big.n_cols, big.nnz, big.Ap, big.Aj, big.Ax.dtype)
     assert q.info()["main_kernel"] == "csr_vector_window_kernel"
     small = sp.synth.banded_fixed(1 << 14, 32, 4096, 1, DEV)
