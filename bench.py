@@ -575,7 +575,11 @@ def main():
         for k, r in runs.items():
             time_steps(r, x, y, use_dist, max(args.warmup, 70))
     run = runs[kind]
-    time_steps(run, x, y, use_dist, max(args.warmup, 1))                     # the W warm-up steps proper, on the kind that is timed
+    # the W warm-up steps proper, on the kind that is timed — at least 100 of them in ONE uninterrupted stream: the probe
+    # above runs in bursts of 10 with a synchronisation between them, and a short timed region (the driver's K = 20 is
+    # 3.5 ms) right behind such bursts measured ~1 % slower than behind 17 ms of continuous executes
+    # (profiles/r03_final_warm.txt: 175.0 / 175.7 us without, 173.9 / 174.5 with 100, 173.1 for K = 200)
+    time_steps(run, x, y, use_dist, max(args.warmup, 100))
 
     dog.phase = "timed region"
     wall, dev_list = time_steps(run, x, y, use_dist, args.steps)            # THE timed region
@@ -633,6 +637,7 @@ def main():
             "value": 2.0 * total_nnz * args.steps / wall / 1e9,
             "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "warmup_executed": max(args.warmup, 100),       # untimed executes of the timed kind right before the region (>= W)
             "ms_per_step": step_ms,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32" if m.Ax.dtype == torch.float32 else "f64",
