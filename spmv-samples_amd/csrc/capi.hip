@@ -118,7 +118,11 @@ static int execute_typed(Plan& p, const void* Ax, const void* x, void* y, hipStr
             if constexpr (sizeof(val_t) == 8)
                 if (p.mat_type == MI355_VAL_F32) return launch_merge<off_t, val_t, float>(p, Ap, static_cast<const float*>(Ax), xx, yy, s);
             return launch_merge<off_t, val_t, val_t>(p, Ap, ax, xx, yy, s);
-        case MI355_KIND_LIGHT:  return launch_light<off_t, val_t>(p, Ap, ax, xx, yy, s);
+        case MI355_KIND_LIGHT:
+            // (a small regular matrix: handing rows out costs more than summing them — the plain one-pass kernel of the
+            // VECTOR kind, plan_create_impl; light's own dequeueing fallback took 29-133 us where this takes 3-6)
+            if (p.small_plain) return launch_vector<off_t, val_t>(p, Ap, ax, xx, yy, s);
+            return launch_light<off_t, val_t>(p, Ap, ax, xx, yy, s);
     }
     set_error("unknown kind %d", p.kind);
     return MI355_SPMV_EINVAL;
@@ -360,7 +364,7 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
         p.window_bytes = w->window_bytes;
         p.window_from_band = w->window_from_band != 0;
         p.sweep = w->window_sweep != 0;
-        p.small_plain = w->small_plain != 0 && kind == MI355_KIND_VECTOR;
+        p.small_plain = w->small_plain != 0;
         p.n_seg = w->window_segments >= 2 ? w->window_segments : 0;
         p.probe_ok = w->probe_ok != 0;
         // (column - row) bands were measured with whole-matrix row numbers; this plan's rows start at 0
@@ -395,7 +399,7 @@ static int plan_create_impl(mi355_spmv_plan** out, int kind, int off_type, int v
             if (p.n_giant > 0) p.n_kernels = 3;
         }
         // a small, regular matrix: the plain one-pass kernel (common.hpp, kSmallPlainNnz); two 4-byte elements per lane and row
-        if (kind == MI355_KIND_VECTOR && !blk && p.knob.small != 0 && p.knob.plain == 0 && !p.balanced && !p.sweep &&
+        if ((kind == MI355_KIND_VECTOR || kind == MI355_KIND_LIGHT) && !blk && p.knob.small != 0 && p.knob.plain == 0 && !p.balanced && !p.sweep &&
             p.n_giant == 0 && p.n_rows > 0 && (p.nnz - p.nnz_begin) <= kSmallPlainNnz) {
             const int64_t mean = (p.nnz - p.nnz_begin) / p.n_rows;
             // lanes per row: two 4-byte elements per lane and row up to 32 per row, four beyond (measured: 32 per row 16 lanes

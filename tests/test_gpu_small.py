@@ -37,6 +37,9 @@ def test_small_matrices_take_the_plain_kernel_and_keep_parity(sp, oracle, small_
         Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, max_len, NP[off], NP[val], long_row=long_row)
         x = (rng.rand(n_cols) * 2 - 1).astype(NP[val])
         nnz = int(Ap[-1])
+        pl = sp.Plan("light", n_rows, n_cols, nnz, d(Ap), d(Aj), d(Ax).dtype)
+        yl = torch.full((n_rows,), float("nan"), dtype=d(Ax).dtype, device=DEV)
+        pl.execute(d(Ax), d(x), yl)
         p = sp.Plan("vector", n_rows, n_cols, nnz, d(Ap), d(Aj), d(Ax).dtype)
         info = p.info()
         if nnz > 0:
@@ -45,6 +48,8 @@ def test_small_matrices_take_the_plain_kernel_and_keep_parity(sp, oracle, small_
         p.execute(d(Ax), d(x), y)
         torch.cuda.synchronize()
         assert_parity(oracle, Ap, Aj, Ax, x, y.cpu().numpy())
+        assert torch.equal(yl, y)                                          # light takes the same kernel here: the same sums
+        pl.destroy()
         # alpha / beta
         p.set_alpha_beta(2.0, -1.0)
         y2 = torch.ones(n_rows, dtype=d(Ax).dtype, device=DEV)
@@ -69,9 +74,10 @@ def test_a_skewed_or_big_matrix_keeps_the_chunked_kernels(sp, small_on):
     small = sp.synth.banded_fixed(1 << 14, 32, 4096, 1, DEV)
     r = sp.Plan("vector", small.n_rows, small.n_cols, small.nnz, small.Ap, small.Aj, small.Ax.dtype)
     assert r.info()["main_kernel"] == "csr_vector_kernel" and r.info()["lanes_per_row"] == 16
-    for k in ("light", "merge"):                                           # the other kinds are what they were
-        t = sp.Plan(k, small.n_rows, small.n_cols, small.nnz, small.Ap, small.Aj, small.Ax.dtype)
-        assert t.info()["main_kernel"] != "csr_vector_kernel"
+    t = sp.Plan("light", small.n_rows, small.n_cols, small.nnz, small.Ap, small.Aj, small.Ax.dtype)
+    assert t.info()["main_kernel"] == "csr_vector_kernel"                  # handing rows out would cost more than summing them
+    t = sp.Plan("merge", small.n_rows, small.n_cols, small.nnz, small.Ap, small.Aj, small.Ax.dtype)
+    assert t.info()["main_kernel"] != "csr_vector_kernel"                  # merge-path is what it was
 
 
 def test_row_blocks_of_a_small_matrix_equal_the_one_gpu_result(sp, small_on):
@@ -83,9 +89,10 @@ def test_row_blocks_of_a_small_matrix_equal_the_one_gpu_result(sp, small_on):
     assert whole.shape().small_plain == 1
     y1 = torch.full((m.n_rows,), float("nan"), device=DEV)
     whole.execute(m.Ax, x, y1)
-    dp = sp.DistPlan.local("vector", m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype, sub_blocks=3)
-    y2 = torch.full((m.n_rows,), float("nan"), device=DEV)
-    dp.execute(m.Ax, x, y2)
-    torch.cuda.synchronize()
-    assert torch.equal(y1, y2) and not torch.isnan(y1).any()
-    dp.destroy()
+    for kind in ("vector", "light"):
+        dp = sp.DistPlan.local(kind, m.n_rows, m.n_cols, m.nnz, m.Ap, m.Aj, m.Ax.dtype, sub_blocks=3)
+        y2 = torch.full((m.n_rows,), float("nan"), device=DEV)
+        dp.execute(m.Ax, x, y2)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y2) and not torch.isnan(y1).any()
+        dp.destroy()
