@@ -233,7 +233,7 @@ typedef struct mi355_spmv_plan_shape {
     int32_t window_elems, window_bytes, window_from_band, window_segments, probe_ok, long_steps;
     int64_t band_lo, band_hi, seg_lo[4], seg_hi[4];
     int32_t window_sweep;             /* 1 = the band is wider than any window: one group of rows per chunk, the window sweeps it */
-    int32_t small_plain;              /* 1 = VECTOR on a small matrix: the plain one-pass kernel (lanes_per_row lanes, 4-byte loads) */
+    int32_t small_plain;              /* 1 = VECTOR / LIGHT on a small matrix: the plain one-pass kernel (lanes_per_row lanes, 4-byte loads) */
 } mi355_spmv_plan_shape;
 int mi355_spmv_plan_get_shape(const mi355_spmv_plan* plan, mi355_spmv_plan_shape* shape);
 /* parts + 1 entries each: row_cuts[p] = first row of block p, chunk_cuts[p] = its first chunk in the plan's

@@ -91,7 +91,7 @@ struct Knobs {
     int giant = -1;            // MI355_SPMV_GIANT            0 = no giant-row slices
     int64_t giant_row = 0;     // MI355_SPMV_GIANT_ROW        nonzeros beyond which a row is giant (>= 4096)
     int plain = 0;             // MI355_SPMV_PLAIN            1 = the 4-byte-per-lane fallback kernels
-    int small = -1;            // MI355_SPMV_SMALL            0 = small matrices keep the chunked kernels too (VECTOR)
+    int small = -1;            // MI355_SPMV_SMALL            0 = small matrices keep the chunked kernels too (VECTOR / LIGHT)
     int64_t rel32_limit = 0;   // MI355_SPMV_REL32_LIMIT      tests: nonzero span beyond which a chunk leaves the 32-bit path
     int light_blocks_per_cu = 0;   // MI355_LIGHT_BLOCKS_PER_CU
     int light_chunk_div = 0;   // MI355_LIGHT_CHUNK_DIV
@@ -189,7 +189,7 @@ struct Plan {
     unsigned long long* counters;  // LIGHT: kXcds shards, one 128-B line each
     bool light_dequeue_once;       // LIGHT, equal-row chunks: one workgroup and one dequeue per chunk (else by index)
     int n_kernels;
-    bool small_plain = false;   // VECTOR: a matrix small enough for the plain one-pass kernel to win (capi.hip, plan_create_impl)
+    bool small_plain = false;   // VECTOR / LIGHT: a matrix small enough for the plain one-pass kernel to win (capi.hip, plan_create_impl)
     char main_kernel[64];
 };
 
